@@ -1,0 +1,690 @@
+// C ABI of libfrhot.so (see include/frhot.h): contexts, model loading, the embed
+// pipeline, galleries and search.  Host-side only; kernels live in frhot_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/frhot.h"
+#include "frhot_kernels.h"
+
+using namespace frhot;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(FRHOT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct LayerSpec { const char* name; int hw, cin, cout, pool, opad; };
+// conv1_1 is handled by its own kernel; the rest go through the implicit GEMM.
+const LayerSpec kConv[] = {
+    {"conv1_1", 224, 3, 64, 0, 1},   {"conv1_2", 224, 64, 64, 1, 1},  {"conv2_1", 112, 64, 128, 0, 1},
+    {"conv2_2", 112, 128, 128, 1, 1}, {"conv3_1", 56, 128, 256, 0, 1}, {"conv3_2", 56, 256, 256, 0, 1},
+    {"conv3_3", 56, 256, 256, 1, 1},  {"conv4_1", 28, 256, 512, 0, 1}, {"conv4_2", 28, 512, 512, 0, 1},
+    {"conv4_3", 28, 512, 512, 1, 1},  {"conv5_1", 14, 512, 512, 0, 1}, {"conv5_2", 14, 512, 512, 0, 1},
+    {"conv5_3", 14, 512, 512, 1, 0},
+};
+constexpr int kNumConv = 13;
+constexpr int kFc6K = 7 * 7 * 512, kFcN = 4096;
+constexpr int kFc6Split = 14, kFc7Split = 8;
+
+// Weight blob: "FRHOTW01", u32 version, u32 count, then `count` entries of
+// {char name[16]; u32 dtype (0 f16, 1 f32); u32 ndim; u32 dims[4]; u64 offset; u64 nbytes}.
+struct BlobEntry { char name[16]; uint32_t dtype, ndim, dims[4]; uint64_t offset, nbytes; };
+static_assert(sizeof(BlobEntry) == 56, "blob entry layout");
+
+const BlobEntry* blob_find(const uint8_t* blob, size_t nbytes, const char* name) {
+    if (nbytes < 16 || memcmp(blob, "FRHOTW01", 8) != 0) return nullptr;
+    uint32_t count;
+    memcpy(&count, blob + 12, 4);
+    if (16 + (size_t)count * sizeof(BlobEntry) > nbytes) return nullptr;
+    const BlobEntry* e = (const BlobEntry*)(blob + 16);
+    for (uint32_t i = 0; i < count; ++i)
+        if (strncmp(e[i].name, name, 16) == 0) {
+            if (e[i].offset + e[i].nbytes > nbytes) return nullptr;
+            return &e[i];
+        }
+    return nullptr;
+}
+
+size_t act_elems(const LayerSpec& l, int B) {
+    const int ho = l.pool ? l.hw / 2 : l.hw;
+    const int p = ho + 2 * l.opad;
+    return (size_t)B * p * p * l.cout;
+}
+
+}  // namespace
+
+struct frhot_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int max_batch = 0;
+    std::mutex mu;
+    bool model = false;
+    float input_scale = 1.0f;
+    // weights
+    void* w[kNumConv] = {};      // fp16 [Cout][9*Cin]; w[0] is the packed [64][48] conv1_1 matrix
+    float* bias[kNumConv] = {};
+    void *w6 = nullptr, *w7 = nullptr;
+    float *b6 = nullptr, *b7 = nullptr;
+    // activations and scratch
+    void* x0 = nullptr;          // fp16 [B,226,226,4]
+    void* act[kNumConv] = {};
+    uint8_t* u8 = nullptr;       // [B,224,224,3]
+    int* img_max = nullptr;
+    CropMeta* meta_dev = nullptr;
+    uint8_t* lut_dev = nullptr;  // [2][256]: identity, gamma 1.5
+    void* fc6_out = nullptr;     // fp16 [B,4096]
+    float* partial = nullptr;    // split-K partial sums
+    // host-call staging
+    uint8_t* crops_dev = nullptr; size_t crops_cap = 0;
+    float* emb_dev = nullptr;    // [B,4096]
+    void* q_dev = nullptr;       // fp16 [B,4096]
+    int32_t* qkeys_dev = nullptr;
+    float* res_s = nullptr; int64_t* res_r = nullptr;  // [B,16]
+    std::vector<CropMeta> meta_host;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[6] = {};
+};
+
+struct frhot_gallery {
+    frhot_ctx* ctx = nullptr;
+    int D = 0;
+    int64_t capacity = 0, nrows = 0;
+    void* rows = nullptr;
+    int32_t* keys = nullptr;
+    float* part_s = nullptr; int64_t* part_r = nullptr; size_t part_cap = 0;
+    // host-call staging
+    float* up_vecs = nullptr; int32_t* up_keys = nullptr; int64_t* up_rows = nullptr; int up_cap = 0;
+    void* q16 = nullptr; float* q32 = nullptr; int32_t* qk = nullptr; float* out_s = nullptr; int64_t* out_r = nullptr;
+    int q_cap = 0;
+};
+
+namespace {
+
+int fill_crop_meta(int h, int w, int stride, int64_t offset, CropMeta* m) {
+    if (h <= 0 || w <= 0 || stride < 3 * w) return fail(FRHOT_EINVAL, "bad crop geometry %dx%d stride %d", h, w, stride);
+    const double f0 = 224.0 / (double)h, f1 = 224.0 / (double)w;
+    const double f = f0 < f1 ? f0 : f1;
+    const int dw = (int)((double)w * f), dh = (int)((double)h * f);
+    if (dw <= 0 || dh <= 0 || dw > 224 || dh > 224)
+        return fail(FRHOT_EINVAL, "crop %dx%d resizes to an empty image", h, w);
+    m->offset = offset; m->h = h; m->w = w; m->stride = stride;
+    m->dw = dw; m->dh = dh;
+    m->pady = (224 - dh) / 2; m->padx = (224 - dw) / 2;
+    m->area2x = (w == 2 * dw && h == 2 * dh) ? 1 : 0;
+    m->scale_x = 1.0 / ((double)dw / (double)w);
+    m->scale_y = 1.0 / ((double)dh / (double)h);
+    return FRHOT_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int upload(void** dst, const void* src, size_t n) {
+    HIP_TRY(hipMalloc(dst, n));
+    HIP_TRY(hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
+    return FRHOT_OK;
+}
+
+// Enqueue the whole embed pipeline for B crops whose pixels sit at crops_dev.
+int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
+                  const int32_t* strides, int B, unsigned flags, float* out_f32, void* out_q, int Dq) {
+    if (!c->model) return fail(FRHOT_ESTATE, "frhot_model_load has not been called");
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    if (!crops_dev || !offsets || !hw || !strides) return fail(FRHOT_EINVAL, "null crop arguments");
+    if (out_q && (Dq <= 0 || Dq > kFcN || Dq % 64)) return fail(FRHOT_EINVAL, "Dq %d must be a multiple of 64 in 64..4096", Dq);
+    c->meta_host.resize(B);
+    for (int i = 0; i < B; ++i) {
+        int rc = fill_crop_meta(hw[2 * i], hw[2 * i + 1], strides[i], offsets[i], &c->meta_host[i]);
+        if (rc) return rc;
+    }
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->meta_dev, c->meta_host.data(), sizeof(CropMeta) * B, hipMemcpyHostToDevice, s));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
+    const uint8_t* lut = c->lut_dev + ((flags & FRHOT_FLAG_GAMMA) ? 256 : 0);
+    HIP_TRY(launch_resize_u8((const uint8_t*)crops_dev, c->meta_dev, lut, (flags & FRHOT_FLAG_NOFLIP) ? 0 : 1, c->u8,
+                             c->img_max, B, s));
+    HIP_TRY(launch_normalize_pack(c->u8, c->img_max, c->input_scale, c->x0, B, s));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
+    HIP_TRY(launch_conv1_1(c->x0, c->w[0], c->bias[0], c->act[0], B, s));
+    for (int l = 1; l < kNumConv; ++l) {
+        ConvLayerDesc d{kConv[l].hw, kConv[l].cin, kConv[l].cout, kConv[l].pool, kConv[l].opad};
+        HIP_TRY(launch_conv3x3(d, c->act[l - 1], c->w[l], c->bias[l], c->act[l], B, s));
+    }
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    HIP_TRY(launch_fc_splitk(c->act[kNumConv - 1], c->w6, c->partial, B, kFcN, kFc6K, kFc6Split, s));
+    HIP_TRY(launch_fc_reduce_relu(c->partial, c->b6, c->fc6_out, B, kFcN, kFc6Split, s));
+    HIP_TRY(launch_fc_splitk(c->fc6_out, c->w7, c->partial, B, kFcN, kFcN, kFc7Split, s));
+    HIP_TRY(launch_fc_reduce_relu_l2(c->partial, c->b7, out_f32, out_q, out_q ? Dq : kFcN, B, kFcN, kFc7Split, s));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], s));
+    return FRHOT_OK;
+}
+
+// Pack host crops tightly into the context's device staging buffer.
+int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, const int32_t* strides, int B,
+                std::vector<int64_t>& offsets, std::vector<int32_t>& packed_strides) {
+    if (!crops || !hw || !strides) return fail(FRHOT_EINVAL, "null crop arguments");
+    offsets.resize(B); packed_strides.resize(B);
+    size_t total = 0;
+    for (int i = 0; i < B; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h <= 0 || w <= 0 || h > 16384 || w > 16384 || strides[i] < 3 * w || !crops[i])
+            return fail(FRHOT_EINVAL, "bad crop %d: %dx%d stride %d", i, h, w, strides[i]);
+        offsets[i] = (int64_t)total;
+        packed_strides[i] = 3 * w;
+        total += ((size_t)h * 3 * w + 15) & ~(size_t)15;
+    }
+    if (total > c->crops_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->crops_dev) HIP_TRY(hipFree(c->crops_dev));
+        c->crops_dev = nullptr; c->crops_cap = 0;
+        const size_t cap = total + total / 4 + 4096;
+        HIP_TRY(hipMalloc((void**)&c->crops_dev, cap));
+        c->crops_cap = cap;
+    }
+    for (int i = 0; i < B; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        HIP_TRY(hipMemcpy2DAsync(c->crops_dev + offsets[i], (size_t)3 * w, crops[i], (size_t)strides[i], (size_t)3 * w,
+                                 (size_t)h, hipMemcpyHostToDevice, c->stream));
+    }
+    return FRHOT_OK;
+}
+
+int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, int Bq, int k, float* scores_dev,
+                   int64_t* rows_dev, int64_t row_base) {
+    frhot_ctx* c = g->ctx;
+    if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
+    if (!q16 || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null search arguments");
+    hipStream_t s = c->stream;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], s));
+    if (g->nrows == 0) {
+        // nothing stored: -inf / -1 everywhere, via the final kernel over one empty list
+        HIP_TRY(hipMemsetAsync(rows_dev, 0xFF, sizeof(int64_t) * (size_t)Bq * k, s));
+        std::vector<float> ninf((size_t)Bq * k, -INFINITY);
+        HIP_TRY(hipMemcpyAsync(scores_dev, ninf.data(), sizeof(float) * ninf.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], s)); HIP_TRY(hipEventRecord(c->ev[5], s)); }
+        return FRHOT_OK;
+    }
+    const int kl = scan_list_len(k);
+    const size_t need = (size_t)scan_max_blocks() * Bq * kl;
+    if (need > g->part_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (g->part_s) HIP_TRY(hipFree(g->part_s));
+        if (g->part_r) HIP_TRY(hipFree(g->part_r));
+        g->part_s = nullptr; g->part_r = nullptr; g->part_cap = 0;
+        HIP_TRY(hipMalloc((void**)&g->part_s, need * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&g->part_r, need * sizeof(int64_t)));
+        g->part_cap = need;
+    }
+    int nblk = 0;
+    HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, Bq, k, g->part_s, g->part_r, &nblk, s));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[4], s));
+    HIP_TRY(launch_topk_final(g->part_s, g->part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[5], s));
+    return FRHOT_OK;
+}
+
+int gallery_grow_query_staging(frhot_gallery* g, int Bq) {
+    if (Bq <= g->q_cap) return FRHOT_OK;
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    void** ptrs[] = {(void**)&g->q16, (void**)&g->q32, (void**)&g->qk, (void**)&g->out_s, (void**)&g->out_r};
+    for (void** p : ptrs) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
+    g->q_cap = 0;
+    const int cap = Bq + Bq / 2 + 16;
+    HIP_TRY(hipMalloc(&g->q16, (size_t)cap * g->D * 2));
+    HIP_TRY(hipMalloc((void**)&g->q32, (size_t)cap * g->D * 4));
+    HIP_TRY(hipMalloc((void**)&g->qk, (size_t)cap * 4));
+    HIP_TRY(hipMalloc((void**)&g->out_s, (size_t)cap * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&g->out_r, (size_t)cap * 16 * 8));
+    g->q_cap = cap;
+    return FRHOT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* frhot_last_error(void) { return g_err.c_str(); }
+
+int frhot_ctx_destroy(frhot_ctx* c);
+
+const char* frhot_version(void) { return "frhot 0.1 gfx950 mfma-f16 igemm/scan"; }
+
+static int ctx_init(frhot_ctx* c) {
+    if (!c->stream) { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    const int B = c->max_batch;
+    const size_t x0_bytes = (size_t)B * 226 * 226 * 4 * 2;
+    HIP_TRY(hipMalloc(&c->x0, x0_bytes));
+    HIP_TRY(hipMemsetAsync(c->x0, 0, x0_bytes, c->stream));
+    for (int l = 0; l < kNumConv; ++l) {
+        const size_t n = act_elems(kConv[l], B) * 2;
+        HIP_TRY(hipMalloc(&c->act[l], n));
+        HIP_TRY(hipMemsetAsync(c->act[l], 0, n, c->stream));
+    }
+    HIP_TRY(hipMalloc((void**)&c->u8, (size_t)B * 224 * 224 * 3));
+    HIP_TRY(hipMalloc((void**)&c->img_max, sizeof(int) * B));
+    HIP_TRY(hipMalloc((void**)&c->meta_dev, sizeof(CropMeta) * B));
+    HIP_TRY(hipMalloc(&c->fc6_out, (size_t)B * kFcN * 2));
+    HIP_TRY(hipMalloc((void**)&c->partial, (size_t)kFc6Split * B * kFcN * 4));
+    HIP_TRY(hipMalloc((void**)&c->emb_dev, (size_t)B * kFcN * 4));
+    HIP_TRY(hipMalloc(&c->q_dev, (size_t)B * kFcN * 2));
+    HIP_TRY(hipMalloc((void**)&c->qkeys_dev, (size_t)B * 4));
+    HIP_TRY(hipMalloc((void**)&c->res_s, (size_t)B * 16 * 4));
+    HIP_TRY(hipMalloc((void**)&c->res_r, (size_t)B * 16 * 8));
+    uint8_t lut[512];
+    for (int i = 0; i < 256; ++i) {
+        lut[i] = (uint8_t)i;
+        // app/src/utils/legacy.py:108-109 with gamma 1.5: float64 pow, truncating cast
+        lut[256 + i] = (uint8_t)(std::pow((double)i / 255.0, 1.0 / 1.5) * 255.0);
+    }
+    HIP_TRY(hipMalloc((void**)&c->lut_dev, 512));
+    HIP_TRY(hipMemcpy(c->lut_dev, lut, 512, hipMemcpyHostToDevice));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FRHOT_OK;
+}
+
+int frhot_ctx_create(int device_id, void* stream, int max_batch, frhot_ctx** out) {
+    if (!out) return fail(FRHOT_EINVAL, "out is null");
+    *out = nullptr;
+    if (max_batch <= 0 || max_batch > 4096) return fail(FRHOT_EINVAL, "max_batch %d outside 1..4096", max_batch);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(FRHOT_EINVAL, "device %d of %d", device_id, ndev);
+    DeviceGuard dg(device_id);
+    if (!dg.ok) return fail(FRHOT_EHIP, "cannot select device %d", device_id);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FRHOT_EHIP, "device %d is %s; this library holds gfx950 code only", device_id, prop.gcnArchName);
+    HIP_TRY(kernels_init());
+    frhot_ctx* c = new frhot_ctx();
+    c->device = device_id;
+    c->max_batch = max_batch;
+    c->stream = (hipStream_t)stream;
+    const int rc = ctx_init(c);
+    if (rc) {
+        const std::string keep = g_err;
+        frhot_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return FRHOT_OK;
+}
+
+int frhot_ctx_destroy(frhot_ctx* c) {
+    if (!c) return FRHOT_OK;
+    DeviceGuard dg(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial, c->crops_dev,
+                    c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->w6, c->w7, c->b6, c->b7};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int l = 0; l < kNumConv; ++l) {
+        if (c->act[l]) (void)hipFree(c->act[l]);
+        if (c->w[l]) (void)hipFree(c->w[l]);
+        if (c->bias[l]) (void)hipFree(c->bias[l]);
+    }
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FRHOT_OK;
+}
+
+int frhot_ctx_sync(frhot_ctx* c) {
+    if (!c) return fail(FRHOT_EINVAL, "ctx is null");
+    DeviceGuard dg(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FRHOT_OK;
+}
+
+int frhot_model_load(frhot_ctx* c, const void* blob_v, size_t nbytes, float input_scale) {
+    if (!c || !blob_v) return fail(FRHOT_EINVAL, "null argument");
+    if (!(input_scale > 0.f) || !std::isfinite(input_scale)) return fail(FRHOT_EINVAL, "input_scale must be positive");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    const uint8_t* blob = (const uint8_t*)blob_v;
+    if (c->model) return fail(FRHOT_ESTATE, "a model is already loaded in this context");
+    auto load_bias = [&](const char* lname, int n, float** dst) -> int {
+        char nm[32];
+        snprintf(nm, sizeof nm, "%s.b", lname);
+        const BlobEntry* e = blob_find(blob, nbytes, nm);
+        if (!e || e->dtype != 1 || e->nbytes != (uint64_t)n * 4) return fail(FRHOT_EINVAL, "blob: bad or missing %s", nm);
+        std::vector<float> b(n);
+        memcpy(b.data(), blob + e->offset, (size_t)n * 4);
+        for (float& v : b) v *= input_scale;
+        return upload((void**)dst, b.data(), (size_t)n * 4);
+    };
+    auto find_w = [&](const char* lname, uint64_t elems) -> const BlobEntry* {
+        char nm[32];
+        snprintf(nm, sizeof nm, "%s.w", lname);
+        const BlobEntry* e = blob_find(blob, nbytes, nm);
+        if (!e || e->dtype != 0 || e->nbytes != elems * 2) { fail(FRHOT_EINVAL, "blob: bad or missing %s", nm); return nullptr; }
+        return e;
+    };
+    for (int l = 0; l < kNumConv; ++l) {
+        const LayerSpec& L = kConv[l];
+        const BlobEntry* e = find_w(L.name, (uint64_t)L.cout * 9 * L.cin);
+        if (!e) return FRHOT_EINVAL;
+        int rc;
+        if (l == 0) {
+            // [64][3][3][3] -> [64][48], k = tap*4 + c, zero elsewhere
+            std::vector<uint16_t> p(64 * 48, 0);
+            const uint16_t* src = (const uint16_t*)(blob + e->offset);
+            for (int n = 0; n < 64; ++n)
+                for (int t = 0; t < 9; ++t)
+                    for (int ch = 0; ch < 3; ++ch) p[n * 48 + t * 4 + ch] = src[(n * 9 + t) * 3 + ch];
+            rc = upload(&c->w[0], p.data(), p.size() * 2);
+        } else {
+            rc = upload(&c->w[l], blob + e->offset, e->nbytes);
+        }
+        if (rc) return rc;
+        rc = load_bias(L.name, L.cout, &c->bias[l]);
+        if (rc) return rc;
+    }
+    const BlobEntry* e6 = find_w("fc6", (uint64_t)kFcN * kFc6K);
+    if (!e6) return FRHOT_EINVAL;
+    int rc = upload(&c->w6, blob + e6->offset, e6->nbytes);
+    if (rc) return rc;
+    const BlobEntry* e7 = find_w("fc7", (uint64_t)kFcN * kFcN);
+    if (!e7) return FRHOT_EINVAL;
+    rc = upload(&c->w7, blob + e7->offset, e7->nbytes);
+    if (rc) return rc;
+    rc = load_bias("fc6", kFcN, &c->b6);
+    if (rc) return rc;
+    rc = load_bias("fc7", kFcN, &c->b7);
+    if (rc) return rc;
+    c->input_scale = input_scale;
+    c->model = true;
+    return FRHOT_OK;
+}
+
+int frhot_embed_dev(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
+                    const int32_t* strides, int B, unsigned flags, void* out_f32_dev, void* out_q_f16_dev, int Dq) {
+    if (!c) return fail(FRHOT_EINVAL, "ctx is null");
+    if (!out_f32_dev && !out_q_f16_dev) return fail(FRHOT_EINVAL, "no output requested");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    return embed_enqueue(c, crops_dev, offsets, hw, strides, B, flags, (float*)out_f32_dev, out_q_f16_dev, Dq);
+}
+
+int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, const int32_t* strides, int B,
+                unsigned flags, float* out) {
+    if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    std::vector<int64_t> offsets; std::vector<int32_t> ps;
+    int rc = stage_crops(c, crops, hw, strides, B, offsets, ps);
+    if (rc) return rc;
+    rc = embed_enqueue(c, c->crops_dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, nullptr, kFcN);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FRHOT_OK;
+}
+
+int frhot_debug_read(frhot_ctx* c, int stage, int B, void* host_out, size_t nbytes) {
+    if (!c || !host_out) return fail(FRHOT_EINVAL, "null argument");
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    const void* src; size_t need;
+    if (stage == 0) { src = c->u8; need = (size_t)B * 224 * 224 * 3; }
+    else if (stage == 1) { src = c->x0; need = (size_t)B * 226 * 226 * 4 * 2; }
+    else if (stage >= 10 && stage < 10 + kNumConv) { src = c->act[stage - 10]; need = act_elems(kConv[stage - 10], B) * 2; }
+    else if (stage == 30) { src = c->fc6_out; need = (size_t)B * kFcN * 2; }
+    else return fail(FRHOT_EINVAL, "unknown stage %d", stage);
+    if (nbytes != need) return fail(FRHOT_EINVAL, "stage %d of %d images is %zu bytes, not %zu", stage, B, need, nbytes);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host_out, src, need, hipMemcpyDeviceToHost));
+    return FRHOT_OK;
+}
+
+int frhot_gallery_create(frhot_ctx* c, int D, int64_t capacity, frhot_gallery** out) {
+    if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
+    *out = nullptr;
+    if (D <= 0 || D % 64 || D > 8192) return fail(FRHOT_EINVAL, "D %d must be a multiple of 64 up to 8192", D);
+    if (capacity <= 0 || capacity > 0x7fffff00LL) return fail(FRHOT_EINVAL, "capacity out of range");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    frhot_gallery* g = new frhot_gallery();
+    g->ctx = c; g->D = D; g->capacity = capacity;
+    hipError_t e = hipMalloc(&g->rows, (size_t)capacity * D * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->keys, (size_t)capacity * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(g->keys, 0xFF, (size_t)capacity * 4, c->stream);  // all dead
+    if (e != hipSuccess) {
+        if (g->rows) (void)hipFree(g->rows);
+        if (g->keys) (void)hipFree(g->keys);
+        delete g;
+        return fail(FRHOT_EHIP, "gallery allocation of %lld x %d failed: %s", (long long)capacity, D, hipGetErrorString(e));
+    }
+    *out = g;
+    return FRHOT_OK;
+}
+
+int frhot_gallery_destroy(frhot_gallery* g) {
+    if (!g) return FRHOT_OK;
+    std::lock_guard<std::mutex> lk(g->ctx->mu);
+    DeviceGuard dg(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    void* ptrs[] = {g->rows, g->keys, g->part_s, g->part_r, g->up_vecs, g->up_keys, g->up_rows,
+                    g->q16, g->q32, g->qk, g->out_s, g->out_r};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete g;
+    return FRHOT_OK;
+}
+
+int64_t frhot_gallery_rows(frhot_gallery* g) { return g ? g->nrows : 0; }
+
+int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* keys, const int64_t* rows, int n) {
+    if (!g || !vecs || !keys || !rows) return fail(FRHOT_EINVAL, "null argument");
+    if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
+    int64_t hi = -1;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= g->capacity) return fail(FRHOT_ECAPACITY, "row %lld outside capacity %lld", (long long)rows[i], (long long)g->capacity);
+        if (keys[i] < 0) return fail(FRHOT_EINVAL, "key %d must be non-negative", keys[i]);
+        if (rows[i] > hi) hi = rows[i];
+    }
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    if (n > g->up_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (g->up_vecs) HIP_TRY(hipFree(g->up_vecs));
+        if (g->up_keys) HIP_TRY(hipFree(g->up_keys));
+        if (g->up_rows) HIP_TRY(hipFree(g->up_rows));
+        g->up_vecs = nullptr; g->up_keys = nullptr; g->up_rows = nullptr; g->up_cap = 0;
+        const int cap = n + n / 2 + 16;
+        HIP_TRY(hipMalloc((void**)&g->up_vecs, (size_t)cap * g->D * 4));
+        HIP_TRY(hipMalloc((void**)&g->up_keys, (size_t)cap * 4));
+        HIP_TRY(hipMalloc((void**)&g->up_rows, (size_t)cap * 8));
+        g->up_cap = cap;
+    }
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(g->up_vecs, vecs, (size_t)n * g->D * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->up_keys, keys, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g->up_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_gallery_upsert(g->up_vecs, g->up_keys, g->up_rows, n, g->rows, g->keys, g->D, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (hi + 1 > g->nrows) g->nrows = hi + 1;
+    return FRHOT_OK;
+}
+
+int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n) {
+    if (!g || !rows) return fail(FRHOT_EINVAL, "null argument");
+    if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
+    for (int i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= g->capacity) return fail(FRHOT_ECAPACITY, "row %lld outside capacity", (long long)rows[i]);
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    int64_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8));
+    hipError_t e = hipMemcpyAsync(d, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_set_keys(d, n, FRHOT_KEY_DEAD, g->keys, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FRHOT_EHIP, "tombstone failed: %s", hipGetErrorString(e));
+    return FRHOT_OK;
+}
+
+int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, int64_t n, int nkeys, int dup_every) {
+    if (!g) return fail(FRHOT_EINVAL, "gallery is null");
+    if (row0 < 0 || n <= 0 || row0 + n > g->capacity) return fail(FRHOT_ECAPACITY, "rows [%lld,%lld) outside capacity %lld", (long long)row0, (long long)(row0 + n), (long long)g->capacity);
+    if (nkeys < 0 || dup_every < 0 || dup_every == 1) return fail(FRHOT_EINVAL, "bad nkeys / dup_every");
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(launch_gallery_fill(g->rows, g->keys, g->D, seed, row0, n, nkeys, dup_every, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (row0 + n > g->nrows) g->nrows = row0 + n;
+    return FRHOT_OK;
+}
+
+int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f16, int32_t* out_keys) {
+    if (!g || !rows || !out_f16) return fail(FRHOT_EINVAL, "null argument");
+    if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
+    for (int i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= g->capacity) return fail(FRHOT_ECAPACITY, "row %lld outside capacity", (long long)rows[i]);
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    int64_t* drows = nullptr; void* dout = nullptr; int32_t* dk = nullptr;
+    hipError_t e = hipMalloc((void**)&drows, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * g->D * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&dk, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(drows, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_gather(g->rows, g->keys, drows, n, g->D, dout, dk, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_f16, dout, (size_t)n * g->D * 2, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && out_keys) e = hipMemcpyAsync(out_keys, dk, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (drows) (void)hipFree(drows);
+    if (dout) (void)hipFree(dout);
+    if (dk) (void)hipFree(dk);
+    if (e != hipSuccess) return fail(FRHOT_EHIP, "gallery read failed: %s", hipGetErrorString(e));
+    return FRHOT_OK;
+}
+
+int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev, int Bq, int k,
+                     void* scores_dev, void* rows_dev, int64_t row_base) {
+    if (!g) return fail(FRHOT_EINVAL, "gallery is null");
+    std::lock_guard<std::mutex> lk(g->ctx->mu);
+    DeviceGuard dg(g->ctx->device);
+    return search_enqueue(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base);
+}
+
+int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq, int k, float* scores, int64_t* rows) {
+    if (!g || !q || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
+    if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    int rc = gallery_grow_query_staging(g, Bq);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(g->q32, q, (size_t)Bq * g->D * 4, hipMemcpyHostToDevice, s));
+    if (qkeys) HIP_TRY(hipMemcpyAsync(g->qk, qkeys, (size_t)Bq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_f32_to_unit_f16(g->q32, g->q16, Bq, g->D, s));
+    rc = search_enqueue(g, g->q16, qkeys ? g->qk : nullptr, Bq, k, g->out_s, g->out_r, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(scores, g->out_s, (size_t)Bq * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(rows, g->out_r, (size_t)Bq * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FRHOT_OK;
+}
+
+int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_dev, int P, int Bq, int k,
+                         void* out_scores_dev, void* out_rows_dev) {
+    if (!c || !scores_dev || !rows_dev || !out_scores_dev || !out_rows_dev) return fail(FRHOT_EINVAL, "null argument");
+    if (P <= 0 || Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "P %d / Bq %d / k %d out of range", P, Bq, k);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(launch_topk_final((const float*)scores_dev, (const int64_t*)rows_dev, P, k, Bq, k, 0,
+                              (float*)out_scores_dev, (int64_t*)out_rows_dev, c->stream));
+    return FRHOT_OK;
+}
+
+int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
+                    const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
+                    float* scores, int64_t* rows) {
+    if (!c || !g || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
+    if (g->ctx != c) return fail(FRHOT_EINVAL, "gallery belongs to another context");
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    if (k <= 0 || k > 16) return fail(FRHOT_EINVAL, "k %d out of range (k <= 16)", k);
+    if (g->D > kFcN) return fail(FRHOT_EINVAL, "gallery dimension %d exceeds the descriptor length", g->D);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    std::vector<int64_t> offsets; std::vector<int32_t> ps;
+    int rc = stage_crops(c, crops, hw, strides, B, offsets, ps);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if (qkeys) HIP_TRY(hipMemcpyAsync(c->qkeys_dev, qkeys, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    rc = embed_enqueue(c, c->crops_dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D);
+    if (rc) return rc;
+    rc = search_enqueue(g, c->q_dev, qkeys ? c->qkeys_dev : nullptr, B, k, c->res_s, c->res_r, 0);
+    if (rc) return rc;
+    if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(scores, c->res_s, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(rows, c->res_r, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FRHOT_OK;
+}
+
+int frhot_ctx_timing(frhot_ctx* c, int enable) {
+    if (!c) return fail(FRHOT_EINVAL, "ctx is null");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    if (enable && !c->timing) {
+        // make every event valid so elapsed-time queries on untouched stages do not fail
+        for (auto& e : c->ev) HIP_TRY(hipEventRecord(e, c->stream));
+    }
+    c->timing = enable != 0;
+    return FRHOT_OK;
+}
+
+int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
+    if (!c || !ms5) return fail(FRHOT_EINVAL, "null argument");
+    if (!c->timing) return fail(FRHOT_ESTATE, "timing is not enabled");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 5; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+        ms5[i] = (e == hipSuccess && ms >= 0.f) ? ms : 0.f;
+    }
+    return FRHOT_OK;
+}
+
+}  // extern "C"

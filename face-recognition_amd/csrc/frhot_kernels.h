@@ -1,0 +1,69 @@
+// Launch wrappers of the HIP kernels behind libfrhot.so (gfx950 only).
+// Every wrapper validates shapes on the host, enqueues on `stream` and returns
+// a hipError_t; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace frhot {
+
+// Geometry of one crop, computed on the host (frhot_api.cpp: fill_crop_meta).
+struct CropMeta {
+    int64_t offset;     // byte offset of the image inside the packed crop buffer
+    int32_t h, w;       // source rows, columns
+    int32_t stride;     // bytes between source rows
+    int32_t dw, dh;     // resized size (aspect fit into 224x224, truncated)
+    int32_t padx, pady; // left / top zero padding
+    int32_t area2x;     // 1: exact 2x downscale -> 2x2 box average
+    double scale_x, scale_y;  // 1/(dw/w), 1/(dh/h) in float64
+};
+
+struct ConvLayerDesc {
+    int hw;       // input (= output before pooling) height and width
+    int cin, cout;
+    int pool;     // 1: 2x2/2 max-pool fused into the epilogue
+    int opad;     // 1: output carries a zero halo of one pixel
+};
+
+hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const uint8_t* lut,
+                            int flip, uint8_t* out_u8, int* out_max, int B, hipStream_t s);
+hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale,
+                                 void* x0_f16, int B, hipStream_t s);
+hipError_t launch_conv1_1(const void* x0, const void* w48, const float* bias, void* y,
+                          int B, hipStream_t s);
+hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias,
+                          void* y, int B, hipStream_t s);
+// Split-K GEMM partial[z][m][n] = sum_{k in slice z} x[m][k] * w[n][k]; M rows of x,
+// N rows of w, K multiple of 64*splitk, N multiple of 128.
+hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M, int N, int K,
+                            int splitk, hipStream_t s);
+hipError_t launch_fc_reduce_relu(const float* partial, const float* bias, void* y_f16,
+                                 int M, int N, int splitk, hipStream_t s);
+// fc7 epilogue: bias + ReLU + L2 norm; writes unit f32 [M,N] and/or fp16 [M,Dq]
+// (leading Dq components re-normalised).
+hipError_t launch_fc_reduce_relu_l2(const float* partial, const float* bias, float* out_f32,
+                                    void* out_q_f16, int Dq, int M, int N, int splitk, hipStream_t s);
+
+hipError_t launch_gallery_upsert(const float* vecs, const int32_t* keys, const int64_t* rows, int n,
+                                 void* g_f16, int32_t* g_keys, int D, hipStream_t s);
+hipError_t launch_gallery_set_keys(const int64_t* rows, int n, int32_t key, int32_t* g_keys, hipStream_t s);
+hipError_t launch_gallery_fill(void* g_f16, int32_t* g_keys, int D, uint64_t seed, int64_t row0,
+                               int64_t n, int nkeys, int dup_every, hipStream_t s);
+hipError_t launch_gallery_gather(const void* g_f16, const int32_t* g_keys, const int64_t* rows, int n,
+                                 int D, void* out_f16, int32_t* out_keys, hipStream_t s);
+hipError_t launch_f32_to_unit_f16(const float* q, void* q_f16, int Bq, int D, hipStream_t s);
+
+// Scan: per-block partial top-k lists into part_s/part_r ([nblk][Bq][k]); returns nblk via *nblk_out.
+int scan_max_blocks();
+hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
+                            const void* q_f16, const int32_t* qkeys, int Bq, int k,
+                            float* part_s, int64_t* part_r, int* nblk_out, hipStream_t s);
+// Length of the per-block candidate lists the scan writes for a request of k (5, 10 or 16).
+int scan_list_len(int k);
+// Final selection over nlists lists of kin (layout [nlists][Bq][kin]) -> best kout per query.
+hipError_t launch_topk_final(const float* cand_s, const int64_t* cand_r, int nlists, int kin, int Bq, int kout,
+                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s);
+
+hipError_t kernels_init();  // sets dynamic-LDS attributes once per process
+
+}  // namespace frhot

@@ -1,0 +1,985 @@
+// HIP kernels of the recognition hot path for MI355X (gfx950, wave64, MFMA).
+//
+// Layout conventions (all device memory):
+//   activations  fp16 NHWC with a one-pixel zero halo: [B, H+2, W+2, C]; kernels
+//                write interiors only, so the halo written at allocation stays 0
+//                and 3x3 "same" convolutions need no bounds checks;
+//   conv weights fp16 [Cout][3][3][Cin]  == GEMM operand [N][K], K = 9*Cin;
+//   fc weights   fp16 [N][K];
+//   gallery      fp16 [rows][D] unit rows + int32 key per row.
+//
+// One GEMM core serves the 3x3 convolutions (implicit GEMM), the two fc layers
+// (split-K) and the gallery scan: 64-deep K steps staged global -> LDS with
+// 16-byte LDS-DMA loads (two stages), XOR-swizzled 128-byte LDS rows read with
+// ds_read_b128, v_mfma_f32_16x16x32_f16 accumulation in fp32.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "frhot_kernels.h"
+
+namespace frhot {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define FR_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- helpers ---
+FR_DEV void glds16(const void* g, void* lds_wave_base) {
+    // 64 lanes x 16 B: lane i's bytes land at lds_wave_base + 16*i.
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+FR_DEV uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch),
+// so give every XCD a contiguous run of logical tiles.  Bijective for any n.
+FR_DEV int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// ------------------------------------------------------------- GEMM core ---
+// A block tile is RX "streamed" rows (pixels / batch rows / gallery rows) by RY
+// "resident" rows (output channels / queries), 64 K-elements per step.  In LDS a
+// tile row is 128 bytes = 8 chunks of 16 B; chunk c of row r is stored at chunk
+// position c ^ (r & 7).  LDS-DMA writes lane-linear, so the swizzle is applied to
+// the per-lane SOURCE address and again to the read address.
+// 256 threads = 4 waves arranged WX x WY; each wave owns (RX/WX) x (RY/WY).
+// X_IS_A: the streamed operand is the MFMA A operand (its rows land in the
+// accumulator registers, the resident operand's rows on the lanes); otherwise
+// the resident operand is A.
+template <int RX, int RY, int WX, int WY, bool X_IS_A>
+struct GemmCore {
+    static_assert(WX * WY == 4, "4 waves");
+    static constexpr int TX = RX / WX, TY = RY / WY;
+    static constexpr int NX = TX / 16, NY = TY / 16;
+    static constexpr int XB = RX * 128, YB = RY * 128, SB = XB + YB;
+    static constexpr int NPX = RX / 32, NPY = RY / 32;   // 1-KiB pieces per wave
+    static_assert(RX % 32 == 0 && RY % 32 == 0, "tile rows");
+
+    float4v acc[NY][NX];
+
+    FR_DEV void zero() {
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // Row (inside the tile) that lane `lane` of wave `wave` stages in piece i.
+    FR_DEV static int stage_row(int wave, int lane, int i) { return 8 * (wave + 4 * i) + (lane >> 3); }
+    // Byte offset inside a source row of the 16-B chunk this lane fetches.
+    FR_DEV static int stage_chunk_bytes(int lane) { return (((lane & 7) ^ (lane >> 3)) << 4); }
+
+    FR_DEV static void issue(char* stage, int wave, const char* const (&xp)[NPX], size_t xoff,
+                             const char* const (&yp)[NPY], size_t yoff) {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) glds16(xp[i] + xoff, stage + (wave + 4 * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) glds16(yp[i] + yoff, stage + XB + (wave + 4 * i) * 1024);
+    }
+
+    FR_DEV void compute(const char* stage, int lane, int wx, int wy) {
+        const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = (((kk * 4 + g0) ^ l7) << 4);
+            half8 fx[NX], fy[NY];
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+                fx[x] = *(const half8*)(stage + (wx * TX + x * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int y = 0; y < NY; ++y)
+                fy[y] = *(const half8*)(stage + XB + (wy * TY + y * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int y = 0; y < NY; ++y)
+#pragma unroll
+                for (int x = 0; x < NX; ++x) {
+                    if (X_IS_A)
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], acc[y][x], 0, 0, 0);
+                    else
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[y], fx[x], acc[y][x], 0, 0, 0);
+                }
+        }
+    }
+};
+
+// ------------------------------------------------------ 3x3 conv (igemm) ---
+// Output pixels are enumerated window-major: m = ((b*H/2 + wy)*W/2 + wx)*4 + dy*2 + dx,
+// so four consecutive m are one 2x2 pooling window and, with pixels on the MFMA
+// lanes, a window is one lane quad.
+template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RX, int RY, int WX, int WY>
+__global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const half_t* __restrict__ x,
+                                                            const half_t* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            half_t* __restrict__ y, int batch) {
+    using Core = GemmCore<RX, RY, WX, WY, false>;
+    constexpr int H = HW, W = HW, PW = W + 2, HALF = W / 2;
+    constexpr int K = 9 * CIN, CPK = CIN / 64, NK = 9 * CPK;
+    constexpr int NT = COUT / RY;
+    static_assert(CIN % 64 == 0 && COUT % RY == 0, "channel tiling");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wx = wave / WY, wy = wave % WY;
+    const long M = (long)batch * H * W;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / NT) * RX;
+    const int n0 = (bid % NT) * RY;
+
+    const char* xp[Core::NPX];
+    const char* yp[Core::NPY];
+    const int cb = Core::stage_chunk_bytes(lane);
+#pragma unroll
+    for (int i = 0; i < Core::NPX; ++i) {
+        long m = m0 + Core::stage_row(wave, lane, i);
+        m = m < M ? m : M - 1;
+        const int b = (int)(m / (H * W));
+        const int rem = (int)(m % (H * W));
+        const int win = rem >> 2, d = rem & 3;
+        const int py = 2 * (win / HALF) + (d >> 1), px = 2 * (win % HALF) + (d & 1);
+        xp[i] = (const char*)x + ((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb;
+    }
+#pragma unroll
+    for (int i = 0; i < Core::NPY; ++i)
+        yp[i] = (const char*)w + ((long)(n0 + Core::stage_row(wave, lane, i)) * K) * 2 + cb;
+
+    Core core;
+    core.zero();
+
+    int r = 0, s = 0, cc = 0;  // tap row, tap column, 64-channel chunk of the NEXT step to stage
+    auto next_xoff = [&]() -> size_t {
+        size_t off = ((size_t)(r * PW + s) * CIN + cc * 64) * 2;
+        if (++cc == CPK) { cc = 0; if (++s == 3) { s = 0; ++r; } }
+        return off;
+    };
+
+    Core::issue(smem, wave, xp, next_xoff(), yp, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < NK - 1; ++ks) {
+        Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, next_xoff(), yp, (size_t)(ks + 1) * 128);
+        core.compute(smem + cur * Core::SB, lane, wx, wy);
+        __syncthreads();
+        cur ^= 1;
+    }
+    core.compute(smem + cur * Core::SB, lane, wx, wy);
+
+    // Epilogue: lane = pixel (lane & 15), registers = 4 consecutive channels.
+    constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
+    constexpr int OW = WO + 2 * OPAD, OH = HO + 2 * OPAD;
+    const int l15 = lane & 15, g0 = lane >> 4;
+#pragma unroll
+    for (int px = 0; px < Core::NX; ++px) {
+        const long m = m0 + wx * Core::TX + px * 16 + l15;
+        const bool live = m < M;
+        const long mm = live ? m : M - 1;
+        const int b = (int)(mm / (H * W));
+        const int rem = (int)(mm % (H * W));
+        const int win = rem >> 2, d = rem & 3;
+        int oy, ox;
+        if (POOL) { oy = win / HALF; ox = win % HALF; }
+        else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
+        half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
+#pragma unroll
+        for (int cy = 0; cy < Core::NY; ++cy) {
+            const int c = n0 + wy * Core::TY + cy * 16 + g0 * 4;
+            const float4v bv = *(const float4v*)(bias + c);
+            float4v v = core.acc[cy][px];
+            if (POOL) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = v[j];
+                    t = fmaxf(t, __shfl_xor(t, 1));
+                    t = fmaxf(t, __shfl_xor(t, 2));
+                    v[j] = t;
+                }
+            }
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(v[j] + bv[j], 0.f);
+            if (live && (!POOL || (lane & 3) == 0)) *(half4*)(orow + c) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------ conv1_1 ------
+// 3 -> 64 channels.  Input fp16 [B,226,226,4] (4th channel zero), weights
+// fp16 [64][48] with k = tap*4 + c for k < 36 and zeros after.  K is covered by one
+// 16x16x32 MFMA (taps 0..7) and one 16x16x16 MFMA (tap 8 + zero padding).
+// Each wave turns 16 consecutive pixels of a row into 16 x 64 outputs per step.
+__global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__ x0,
+                                                      const half_t* __restrict__ w48,
+                                                      const float* __restrict__ bias,
+                                                      half_t* __restrict__ y, int ntiles) {
+    constexpr int P = 226, T = 14;  // padded width, 16-pixel tiles per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    half8 a32[4];
+    half4 a16[4];
+    float4v bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const half_t* wr = w48 + (ct * 16 + l15) * 48;
+        a32[ct] = *(const half8*)(wr + 8 * g);
+        a16[ct] = *(const half4*)(wr + 32 + 4 * g);
+        bv[ct] = *(const float4v*)(bias + ct * 16 + g * 4);
+    }
+    const int t0 = 2 * g, t1 = 2 * g + 1;
+    const int off0 = ((t0 / 3) * P + (t0 % 3)) * 4, off1 = ((t1 / 3) * P + (t1 % 3)) * 4;
+    const int off8 = (2 * P + 2) * 4;
+    const int nw = gridDim.x * 4;
+    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
+        const int b = t / (224 * T), rem = t % (224 * T);
+        const int py = rem / T, px = (rem % T) * 16 + l15;
+        const half_t* src = x0 + (((long)b * P + py) * P + px) * 4;
+        const half4 v0 = *(const half4*)(src + off0);
+        const half4 v1 = *(const half4*)(src + off1);
+        const half4 v8 = *(const half4*)(src + off8);
+        const half8 bf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        half_t* dst = y + (((long)b * P + py + 1) * P + px + 1) * 64 + g * 4;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float4v acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[ct], bf, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[ct], v8, acc, 0, 0, 0);
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(acc[j] + bv[ct][j], 0.f);
+            *(half4*)(dst + ct * 16) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------- fc layers ---
+// partial[z][m][n] over K slice z.  Rows of x beyond M are clamped on load and
+// dropped on store.
+template <int RX, int RY, int WX, int WY>
+__global__ __launch_bounds__(256) void fc_splitk_kernel(const half_t* __restrict__ x,
+                                                        const half_t* __restrict__ w,
+                                                        float* __restrict__ partial, int M, int N, int K,
+                                                        int ksteps_per_split) {
+    using Core = GemmCore<RX, RY, WX, WY, false>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wx = wave / WY, wy = wave % WY;
+    const int n0 = blockIdx.x * RY, m0 = blockIdx.y * RX, z = blockIdx.z;
+    const int cb = Core::stage_chunk_bytes(lane);
+    const char* xp[Core::NPX];
+    const char* yp[Core::NPY];
+    const size_t kbase = (size_t)z * ksteps_per_split * 128;
+#pragma unroll
+    for (int i = 0; i < Core::NPX; ++i) {
+        int m = m0 + Core::stage_row(wave, lane, i);
+        m = m < M ? m : M - 1;
+        xp[i] = (const char*)x + (size_t)m * K * 2 + kbase + cb;
+    }
+#pragma unroll
+    for (int i = 0; i < Core::NPY; ++i)
+        yp[i] = (const char*)w + (size_t)(n0 + Core::stage_row(wave, lane, i)) * K * 2 + kbase + cb;
+
+    Core core;
+    core.zero();
+    Core::issue(smem, wave, xp, 0, yp, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < ksteps_per_split - 1; ++ks) {
+        Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, (size_t)(ks + 1) * 128, yp, (size_t)(ks + 1) * 128);
+        core.compute(smem + cur * Core::SB, lane, wx, wy);
+        __syncthreads();
+        cur ^= 1;
+    }
+    core.compute(smem + cur * Core::SB, lane, wx, wy);
+
+    const int l15 = lane & 15, g0 = lane >> 4;
+#pragma unroll
+    for (int px = 0; px < Core::NX; ++px) {
+        const int m = m0 + wx * Core::TX + px * 16 + l15;
+        if (m >= M) continue;
+        float* prow = partial + ((size_t)z * M + m) * N;
+#pragma unroll
+        for (int cy = 0; cy < Core::NY; ++cy) {
+            const int c = n0 + wy * Core::TY + cy * 16 + g0 * 4;
+            *(float4v*)(prow + c) = core.acc[cy][px];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_reduce_relu_kernel(const float* __restrict__ partial,
+                                                             const float* __restrict__ bias,
+                                                             half_t* __restrict__ y, int M, int N, int splitk) {
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
+    const size_t total4 = (size_t)M * N / 4;
+    if (i4 >= total4) return;
+    const int n = (int)((i4 * 4) % N);
+    float4v acc = *(const float4v*)(bias + n);
+    for (int z = 0; z < splitk; ++z) acc += *(const float4v*)(partial + (size_t)z * M * N + i4 * 4);
+    half4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(acc[j], 0.f);
+    *(half4*)(y + i4 * 4) = o;
+}
+
+FR_DEV float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One block per batch row; N == 4096 (16 values per thread).
+__global__ __launch_bounds__(256) void fc_reduce_relu_l2_kernel(const float* __restrict__ partial,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out_f32,
+                                                                half_t* __restrict__ out_q, int Dq, int M,
+                                                                int N, int splitk) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float4v v[4];
+    float ss = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = (i * 256 + tid) * 4;
+        float4v acc = *(const float4v*)(bias + n);
+        for (int z = 0; z < splitk; ++z) acc += *(const float4v*)(partial + ((size_t)z * M + m) * N + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = fmaxf(acc[j], 0.f);
+            ss += acc[j] * acc[j];
+            if (n + j < Dq) ssq += acc[j] * acc[j];
+        }
+        v[i] = acc;
+    }
+    const float tot = block_sum_256(ss, red);
+    const float totq = block_sum_256(ssq, red);
+    const float inv = tot > 0.f ? 1.0f / sqrtf(tot) : 1.0f;
+    const float invq = totq > 0.f ? 1.0f / sqrtf(totq) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = (i * 256 + tid) * 4;
+        if (out_f32) *(float4v*)(out_f32 + (size_t)m * N + n) = v[i] * inv;
+        if (out_q && n < Dq) {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)(v[i][j] * invq);
+            *(half4*)(out_q + (size_t)m * Dq + n) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------ preprocess ---
+// Stage 1: gamma LUT + channel order + cv2-style INTER_LINEAR (11-bit fixed point)
+// resize + centred zero pad, uint8 in -> uint8 [B,224,224,3] out, plus the per-image
+// maximum byte (DeepFace divides by 255 only when it exceeds 1).
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ crops,
+                                                        const CropMeta* __restrict__ meta,
+                                                        const uint8_t* __restrict__ lut, int flip,
+                                                        uint8_t* __restrict__ out, int* __restrict__ out_max) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;  // pixel inside 224x224
+    const CropMeta mt = meta[b];
+    int vmax = 0;
+    if (p < 224 * 224) {
+        const int oy = p / 224, ox = p % 224;
+        const int dy = oy - mt.pady, dx = ox - mt.padx;
+        uint8_t res[3] = {0, 0, 0};
+        if (dy >= 0 && dy < mt.dh && dx >= 0 && dx < mt.dw) {
+            const uint8_t* src = crops + mt.offset;
+            if (mt.area2x) {
+                const uint8_t* r0 = src + (size_t)(2 * dy) * mt.stride + 6 * dx;
+                const uint8_t* r1 = r0 + mt.stride;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int sc = flip ? 2 - c : c;
+                    const int sum = lut[r0[sc]] + lut[r0[3 + sc]] + lut[r1[sc]] + lut[r1[3 + sc]];
+                    res[c] = (uint8_t)((sum + 2) >> 2);
+                }
+            } else {
+                float fx = (float)(((double)dx + 0.5) * mt.scale_x - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= (float)sx;
+                if (sx < 0) { fx = 0.f; sx = 0; }
+                if (sx >= mt.w - 1) { fx = 0.f; sx = mt.w - 1; }
+                const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+                const int sx1 = min(sx + 1, mt.w - 1);
+                float fy = (float)(((double)dy + 0.5) * mt.scale_y - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= (float)sy;
+                const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
+                const int sy0 = min(max(sy, 0), mt.h - 1), sy1 = min(max(sy + 1, 0), mt.h - 1);
+                const uint8_t* r0 = src + (size_t)sy0 * mt.stride;
+                const uint8_t* r1 = src + (size_t)sy1 * mt.stride;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int sc = flip ? 2 - c : c;
+                    const int s0 = lut[r0[3 * sx + sc]] * a0 + lut[r0[3 * sx1 + sc]] * a1;
+                    const int s1 = lut[r1[3 * sx + sc]] * a0 + lut[r1[3 * sx1 + sc]] * a1;
+                    res[c] = (uint8_t)((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2);
+                }
+            }
+        }
+        uint8_t* o = out + ((size_t)b * 224 * 224 + p) * 3;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        vmax = max(max((int)res[0], (int)res[1]), (int)res[2]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o));
+    if ((threadIdx.x & 63) == 0 && vmax > 0) atomicMax(out_max + b, vmax);
+}
+
+// Stage 2: float conversion (x/255 when the image maximum exceeds 1, *255, minus the
+// VGGFace2 channel means), input scale, fp16, into the interior of [B,226,226,4].
+__global__ __launch_bounds__(256) void normalize_pack_kernel(const uint8_t* __restrict__ u8,
+                                                             const int* __restrict__ img_max, float scale,
+                                                             half_t* __restrict__ x0) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= 224 * 224) return;
+    const uint8_t* s = u8 + ((size_t)b * 224 * 224 + p) * 3;
+    const bool div = img_max[b] > 1;
+    const float mean[3] = {91.4953f, 103.8827f, 131.0912f};
+    half4 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (float)s[c];
+        if (div) v = __fdiv_rn(v, 255.0f);
+        v = __fmul_rn(v, 255.0f);
+        v = __fsub_rn(v, mean[c]);
+        o[c] = (half_t)__fmul_rn(v, scale);
+    }
+    o[3] = (half_t)0.f;
+    const int oy = p / 224, ox = p % 224;
+    *(half4*)(x0 + (((size_t)b * 226 + oy + 1) * 226 + ox + 1) * 4) = o;
+}
+
+// --------------------------------------------------------------- gallery ---
+// One wave per row: normalise an f32 row and store it as fp16.
+__global__ __launch_bounds__(256) void gallery_upsert_kernel(const float* __restrict__ vecs,
+                                                             const int32_t* __restrict__ keys,
+                                                             const int64_t* __restrict__ rows, int n,
+                                                             half_t* __restrict__ g, int32_t* __restrict__ gk,
+                                                             int D) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* v = vecs + (size_t)i * D;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float nrm = __fsqrt_rn(ss);
+    const float inv = nrm < 1e-30f ? 1.0f : __fdiv_rn(1.0f, nrm);
+    const int64_t r = rows ? rows[i] : i;
+    half_t* dst = g + (size_t)r * D;
+    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fmul_rn(v[c], inv);
+    if (lane == 0 && gk) gk[r] = keys ? keys[i] : 0;
+}
+
+__global__ void gallery_set_keys_kernel(const int64_t* __restrict__ rows, int n, int32_t key,
+                                        int32_t* __restrict__ gk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gk[rows[i]] = key;
+}
+
+FR_DEV int synth_value(uint64_t seed, uint64_t row, int D, int col) {
+    const uint64_t h = splitmix64(seed + row * (uint64_t)D + (uint64_t)col);
+    return (int)(h & 255) + (int)((h >> 8) & 255) + (int)((h >> 16) & 255) + (int)((h >> 24) & 255) - 510;
+}
+
+// Deterministic synthetic gallery: integer values from a hash, exact integer sum of
+// squares, one IEEE sqrt + divide + multiply per element, so a numpy restatement
+// reproduces every stored half exactly.
+__global__ __launch_bounds__(256) void gallery_fill_kernel(half_t* __restrict__ g, int32_t* __restrict__ gk,
+                                                           int D, uint64_t seed, int64_t row0, int64_t n,
+                                                           int nkeys, int dup_every) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int64_t r = row0 + i;
+    const uint64_t src = (dup_every > 0 && r > 0 && (r % dup_every) == dup_every - 1) ? (uint64_t)(r - 1) : (uint64_t)r;
+    unsigned long long ss = 0;
+    for (int c = lane; c < D; c += 64) {
+        const int v = synth_value(seed, src, D, c);
+        ss += (unsigned long long)(v * v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float nrm = __fsqrt_rn((float)ss);
+    const float inv = ss == 0 ? 1.0f : __fdiv_rn(1.0f, nrm);
+    half_t* dst = g + (size_t)r * D;
+    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fmul_rn((float)synth_value(seed, src, D, c), inv);
+    if (lane == 0) gk[r] = nkeys > 0 ? (int32_t)(splitmix64(seed ^ (src * 0xD1B54A32D192ED03ull)) % (uint64_t)nkeys) : 0;
+}
+
+__global__ __launch_bounds__(256) void gallery_gather_kernel(const half_t* __restrict__ g,
+                                                             const int32_t* __restrict__ gk,
+                                                             const int64_t* __restrict__ rows, int n, int D,
+                                                             half_t* __restrict__ out, int32_t* __restrict__ out_keys) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int64_t r = rows[i];
+    for (int c = lane; c < D; c += 64) out[(size_t)i * D + c] = g[(size_t)r * D + c];
+    if (lane == 0 && out_keys) out_keys[i] = gk[r];
+}
+
+__global__ __launch_bounds__(256) void f32_to_unit_f16_kernel(const float* __restrict__ q, half_t* __restrict__ o,
+                                                              int Bq, int D) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= Bq) return;
+    const float* v = q + (size_t)i * D;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) ss += __shfl_xor(ss, o2);
+    const float nrm = __fsqrt_rn(ss);
+    const float inv = nrm < 1e-30f ? 1.0f : __fdiv_rn(1.0f, nrm);
+    for (int c = lane; c < D; c += 64) o[(size_t)i * D + c] = (half_t)__fmul_rn(v[c], inv);
+}
+
+// ------------------------------------------------------------ scan+top-k ---
+template <int K>
+struct TopK {
+    float s[K];
+    int r[K];
+    FR_DEV void init() {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { s[i] = -INFINITY; r[i] = -1; }
+    }
+    // Precondition: (v,row) beats the tail.  `tie` adds the ascending-row order
+    // inside equal scores (needed when candidates do not arrive in row order).
+    template <bool TIE>
+    FR_DEV void push(float v, int row) {
+        s[K - 1] = v; r[K - 1] = row;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+            const bool sw = s[i] > s[i - 1] || (TIE && s[i] == s[i - 1] && (unsigned)r[i] < (unsigned)r[i - 1]);
+            const float ts = s[i - 1]; const int tr = r[i - 1];
+            s[i - 1] = sw ? s[i] : ts; r[i - 1] = sw ? r[i] : tr;
+            s[i] = sw ? ts : s[i];     r[i] = sw ? tr : r[i];
+        }
+    }
+    FR_DEV bool beats_tail(float v, int row) const {
+        return v > s[K - 1] || (v == s[K - 1] && (unsigned)row < (unsigned)r[K - 1]);
+    }
+};
+
+// Gallery tile = 256 rows (MFMA A operand: rows land in accumulator registers), query
+// tile = 64 queries (B operand: one query per lane & 15).  Waves 2 x 2: each wave owns
+// 128 gallery rows x 32 queries, i.e. two top-k lists per lane.  A block walks gallery
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ... and finally merges its lanes' lists per
+// query into one list of K per (block, query).
+template <int K>
+__global__ __launch_bounds__(256) void scan_topk_kernel(const half_t* __restrict__ gal,
+                                                        const int32_t* __restrict__ gkeys, long nrows, int D,
+                                                        const half_t* __restrict__ q,
+                                                        const int32_t* __restrict__ qkeys, int Bq,
+                                                        float* __restrict__ part_s, long long* __restrict__ part_r) {
+    using Core = GemmCore<256, 64, 2, 2, true>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wx = wave >> 1, wy = wave & 1;
+    const int l15 = lane & 15, g0 = lane >> 4;
+    const int q0 = blockIdx.y * 64;
+    const int nk = D / 64;
+    const long ntiles = (nrows + 255) / 256;
+    const int cb = Core::stage_chunk_bytes(lane);
+
+    const char* yp[Core::NPY];
+#pragma unroll
+    for (int i = 0; i < Core::NPY; ++i) {
+        int qq = q0 + Core::stage_row(wave, lane, i);
+        qq = qq < Bq ? qq : Bq - 1;
+        yp[i] = (const char*)q + (size_t)qq * D * 2 + cb;
+    }
+    int myq[2], mykey[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        myq[y] = q0 + wy * 32 + y * 16 + l15;
+        mykey[y] = (qkeys && myq[y] < Bq) ? qkeys[myq[y]] : -2;
+    }
+    TopK<K> top[2];
+    top[0].init(); top[1].init();
+
+    Core core;
+    long tile = blockIdx.x;
+    if (tile < ntiles) {
+        const char* xp[Core::NPX];
+        auto set_rows = [&](long t) {
+#pragma unroll
+            for (int i = 0; i < Core::NPX; ++i) {
+                long rr = t * 256 + Core::stage_row(wave, lane, i);
+                rr = rr < nrows ? rr : nrows - 1;
+                xp[i] = (const char*)gal + (size_t)rr * D * 2 + cb;
+            }
+        };
+        set_rows(tile);
+        core.zero();
+        Core::issue(smem, wave, xp, 0, yp, 0);
+        __syncthreads();
+        int cur = 0, ks = 0;
+        while (true) {
+            // stage the next (tile, k-step), if any
+            const bool last_k = (ks == nk - 1);
+            const long ntile = tile + gridDim.x;
+            const bool more = !last_k || ntile < ntiles;
+            if (more) {
+                if (last_k) {
+                    set_rows(ntile);
+                    Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, 0, yp, 0);
+                } else {
+                    Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, (size_t)(ks + 1) * 128, yp,
+                                (size_t)(ks + 1) * 128);
+                }
+            }
+            core.compute(smem + cur * Core::SB, lane, wx, wy);
+            if (last_k) {
+                // fold this tile's scores into the per-lane lists
+                const long rbase = tile * 256 + wx * 128 + g0 * 4;
+#pragma unroll
+                for (int x = 0; x < Core::NX; ++x) {
+                    const long r0 = rbase + x * 16;
+                    int4 kv = make_int4(0, 0, 0, 0);
+                    if (gkeys) {
+                        if (r0 + 3 < nrows) kv = *(const int4*)(gkeys + r0);
+                        else {
+                            kv.x = r0 < nrows ? gkeys[r0] : -1;
+                            kv.y = r0 + 1 < nrows ? gkeys[r0 + 1] : -1;
+                            kv.z = r0 + 2 < nrows ? gkeys[r0 + 2] : -1;
+                            kv.w = -1;
+                        }
+                    }
+                    const int kk[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = (r0 + j < nrows) &&
+                                            (mykey[y] == -2 ? kk[j] >= 0 : kk[j] == mykey[y]);
+                            const float v = ok ? core.acc[y][x][j] : -INFINITY;
+                            if (v > top[y].s[K - 1]) top[y].template push<false>(v, (int)(r0 + j));
+                        }
+                    }
+                }
+                core.zero();
+            }
+            if (!more) break;
+            __syncthreads();
+            cur ^= 1;
+            if (last_k) { ks = 0; tile = ntile; } else { ++ks; }
+        }
+    }
+
+    // merge the 8 lists of each query (2 wave rows x 4 lane groups) through LDS
+    __syncthreads();
+    float* ls = (float*)smem;                  // [64 queries][8 lists][K]
+    int* lr = (int*)(smem + 64 * 8 * K * 4);
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int ql = wy * 32 + y * 16 + l15, slot = wx * 4 + g0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ls[(ql * 8 + slot) * K + i] = top[y].s[i];
+            lr[(ql * 8 + slot) * K + i] = top[y].r[i];
+        }
+    }
+    __syncthreads();
+    if (tid < 64 && q0 + tid < Bq) {
+        TopK<K> m;
+        m.init();
+        for (int c = 0; c < 8 * K; ++c) {
+            const float v = ls[tid * 8 * K + c];
+            const int rr = lr[tid * 8 * K + c];
+            if (rr >= 0 && m.beats_tail(v, rr)) m.template push<true>(v, rr);
+        }
+        const size_t o = ((size_t)blockIdx.x * Bq + q0 + tid) * K;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { part_s[o + i] = m.s[i]; part_r[o + i] = m.r[i]; }
+    }
+}
+
+// One wave per query: select the best kout of nlists*kin candidates.
+template <int K>
+__global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict__ cs,
+                                                        const long long* __restrict__ cr, int nlists, int kin,
+                                                        int Bq, int kout, long long row_base,
+                                                        float* __restrict__ out_s, long long* __restrict__ out_r) {
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    // rows are compared as 64-bit values here: keep them beside the int list as (hi, lo)
+    float s[K]; long long r[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { s[i] = -INFINITY; r[i] = -1; }
+    const int total = nlists * kin;
+    for (int c = lane; c < total; c += 64) {
+        const int p = c / kin, j = c % kin;
+        const size_t a = ((size_t)p * Bq + qi) * kin + j;
+        const float v = cs[a];
+        const long long rr = cr[a];
+        if (rr < 0) continue;
+        const bool beats = v > s[K - 1] || (v == s[K - 1] && (r[K - 1] < 0 || rr < r[K - 1]));
+        if (!beats) continue;
+        s[K - 1] = v; r[K - 1] = rr;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+            const bool sw = s[i] > s[i - 1] || (s[i] == s[i - 1] && (r[i - 1] < 0 || r[i] < r[i - 1]));
+            const float ts = s[i - 1]; const long long tr = r[i - 1];
+            s[i - 1] = sw ? s[i] : ts; r[i - 1] = sw ? r[i] : tr;
+            s[i] = sw ? ts : s[i];     r[i] = sw ? tr : r[i];
+        }
+    }
+    for (int o = 0; o < kout; ++o) {
+        float bs = s[0]; long long br = r[0]; int bl = lane;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float os = __shfl_xor(bs, d);
+            const long long orr = __shfl_xor(br, d);
+            const int ol = __shfl_xor(bl, d);
+            const bool take = (orr >= 0) && (br < 0 || os > bs || (os == bs && (orr < br || (orr == br && ol < bl))));
+            if (take) { bs = os; br = orr; bl = ol; }
+        }
+        if (lane == 0) {
+            out_s[(size_t)qi * kout + o] = br >= 0 ? bs : -INFINITY;
+            out_r[(size_t)qi * kout + o] = br >= 0 ? br + row_base : -1;
+        }
+        if (lane == bl && br >= 0) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) { s[i] = s[i + 1]; r[i] = r[i + 1]; }
+            s[K - 1] = -INFINITY; r[K - 1] = -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launch ---
+#define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RX, int RY, int WX, int WY>
+static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, int B, hipStream_t s,
+                                   bool set_attr_only) {
+    using Core = GemmCore<RX, RY, WX, WY, false>;
+    auto kern = conv3x3_igemm_kernel<HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY>;
+    constexpr int lds = 2 * Core::SB;
+    if (set_attr_only)
+        return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const long M = (long)B * HW * HW;
+    const long mt = (M + RX - 1) / RX;
+    const long nblk = mt * (COUT / RY);
+    if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, (const half_t*)x, (const half_t*)w, bias,
+                       (half_t*)y, B);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y,
+                                int B, hipStream_t s, bool attr) {
+#define FR_CONV(HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY)                                                  \
+    if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD)           \
+        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY>(x, w, bias, y, B, s, attr);
+    FR_CONV(224, 64, 64, true, 1, 256, 64, 4, 1)
+    FR_CONV(112, 64, 128, false, 1, 256, 128, 2, 2)
+    FR_CONV(112, 128, 128, true, 1, 256, 128, 2, 2)
+    FR_CONV(56, 128, 256, false, 1, 256, 128, 2, 2)
+    FR_CONV(56, 256, 256, false, 1, 256, 128, 2, 2)
+    FR_CONV(56, 256, 256, true, 1, 256, 128, 2, 2)
+    FR_CONV(28, 256, 512, false, 1, 256, 128, 2, 2)
+    FR_CONV(28, 512, 512, false, 1, 256, 128, 2, 2)
+    FR_CONV(28, 512, 512, true, 1, 256, 128, 2, 2)
+    FR_CONV(14, 512, 512, false, 1, 256, 128, 2, 2)
+    FR_CONV(14, 512, 512, true, 0, 256, 128, 2, 2)
+#undef FR_CONV
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y, int B,
+                          hipStream_t s) {
+    if (B <= 0 || !x || !w || !bias || !y) return hipErrorInvalidValue;
+    return conv_dispatch(d, x, w, bias, y, B, s, false);
+}
+
+hipError_t launch_conv1_1(const void* x0, const void* w48, const float* bias, void* y, int B, hipStream_t s) {
+    if (B <= 0 || !x0 || !w48 || !bias || !y) return hipErrorInvalidValue;
+    const long ntiles = (long)B * 224 * 14;
+    if (ntiles > 0x7fffffffL) return hipErrorInvalidValue;
+    const int blocks = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
+    hipLaunchKernelGGL(conv1_1_kernel, dim3(blocks), dim3(256), 0, s, (const half_t*)x0, (const half_t*)w48, bias,
+                       (half_t*)y, (int)ntiles);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+using FcCore = GemmCore<256, 128, 2, 2, false>;
+
+hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M, int N, int K, int splitk,
+                            hipStream_t s) {
+    if (M <= 0 || N <= 0 || N % 128 || splitk <= 0 || K % (64 * splitk) || !x || !w || !partial)
+        return hipErrorInvalidValue;
+    const int kper = K / 64 / splitk;
+    dim3 grid(N / 128, (M + 255) / 256, splitk);
+    hipLaunchKernelGGL((fc_splitk_kernel<256, 128, 2, 2>), grid, dim3(256), 2 * FcCore::SB, s, (const half_t*)x,
+                       (const half_t*)w, partial, M, N, K, kper);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_fc_reduce_relu(const float* partial, const float* bias, void* y, int M, int N, int splitk,
+                                 hipStream_t s) {
+    if (M <= 0 || N <= 0 || N % 4 || !partial || !bias || !y) return hipErrorInvalidValue;
+    const size_t total4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(fc_reduce_relu_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, bias,
+                       (half_t*)y, M, N, splitk);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_fc_reduce_relu_l2(const float* partial, const float* bias, float* out_f32, void* out_q, int Dq,
+                                    int M, int N, int splitk, hipStream_t s) {
+    if (M <= 0 || N != 4096 || Dq <= 0 || Dq > N || Dq % 4 || !partial || !bias) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fc_reduce_relu_l2_kernel, dim3(M), dim3(256), 0, s, partial, bias, out_f32, (half_t*)out_q, Dq,
+                       M, N, splitk);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const uint8_t* lut, int flip, uint8_t* out,
+                            int* out_max, int B, hipStream_t s) {
+    if (B <= 0 || !crops || !meta || !lut || !out || !out_max) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(out_max, 0, sizeof(int) * (size_t)B, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(196, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale, void* x0, int B, hipStream_t s) {
+    if (B <= 0 || !u8 || !img_max || !x0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(normalize_pack_kernel, dim3(196, B), dim3(256), 0, s, u8, img_max, scale, (half_t*)x0);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_gallery_upsert(const float* vecs, const int32_t* keys, const int64_t* rows, int n, void* g,
+                                 int32_t* gk, int D, hipStream_t s) {
+    if (n <= 0 || !vecs || !g || D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_upsert_kernel, dim3((n + 3) / 4), dim3(256), 0, s, vecs, keys, rows, n, (half_t*)g, gk,
+                       D);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_gallery_set_keys(const int64_t* rows, int n, int32_t key, int32_t* gk, hipStream_t s) {
+    if (n <= 0 || !rows || !gk) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_set_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rows, n, key, gk);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_gallery_fill(void* g, int32_t* gk, int D, uint64_t seed, int64_t row0, int64_t n, int nkeys,
+                               int dup_every, hipStream_t s) {
+    if (n <= 0 || !g || !gk || D % 64 || row0 < 0) return hipErrorInvalidValue;
+    const int64_t blocks = (n + 3) / 4;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (half_t*)g, gk, D, seed, row0, n,
+                       nkeys, dup_every);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_gallery_gather(const void* g, const int32_t* gk, const int64_t* rows, int n, int D, void* out,
+                                 int32_t* out_keys, hipStream_t s) {
+    if (n <= 0 || !g || !rows || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const half_t*)g, gk, rows, n, D,
+                       (half_t*)out, out_keys);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStream_t s) {
+    if (Bq <= 0 || !q || !o || D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(f32_to_unit_f16_kernel, dim3((Bq + 3) / 4), dim3(256), 0, s, q, (half_t*)o, Bq, D);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+using ScanCore = GemmCore<256, 64, 2, 2, true>;
+static constexpr int kScanLds = 2 * ScanCore::SB;  // 80 KiB >= merge area (64*8*16*8 = 64 KiB)
+
+int scan_max_blocks() { return 512; }
+
+static int scan_klist(int k) { return k <= 5 ? 5 : (k <= 10 ? 10 : 16); }
+int scan_list_len(int k) { return scan_klist(k); }
+
+hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
+                            const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r, int* nblk_out,
+                            hipStream_t s) {
+    if (nrows <= 0 || nrows > 0x7fffff00L || D <= 0 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q || !part_s ||
+        !part_r || !nblk_out)
+        return hipErrorInvalidValue;
+    const long ntiles = (nrows + 255) / 256;
+    const int qtiles = (Bq + 63) / 64;
+    long nb = scan_max_blocks() / (qtiles < 8 ? qtiles : 8);
+    if (nb < 64) nb = 64;
+    if (nb > ntiles) nb = ntiles;
+    *nblk_out = (int)nb;
+    dim3 grid((unsigned)nb, qtiles);
+    const int kl = scan_klist(k);
+    if (kl == 5)
+        hipLaunchKernelGGL((scan_topk_kernel<5>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
+                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
+    else if (kl == 10)
+        hipLaunchKernelGGL((scan_topk_kernel<10>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
+                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
+    else
+        hipLaunchKernelGGL((scan_topk_kernel<16>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
+                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
+                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s) {
+    if (nlists <= 0 || kin <= 0 || kin > 16 || Bq <= 0 || kout <= 0 || kout > kin || !cs || !cr || !out_s || !out_r)
+        return hipErrorInvalidValue;
+    const int kl = scan_klist(kin);
+    if (kl == 5)
+        hipLaunchKernelGGL((topk_final_kernel<5>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin, Bq,
+                           kout, (long long)row_base, out_s, (long long*)out_r);
+    else if (kl == 10)
+        hipLaunchKernelGGL((topk_final_kernel<10>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r);
+    else
+        hipLaunchKernelGGL((topk_final_kernel<16>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t kernels_init() {
+    static const ConvLayerDesc layers[] = {
+        {224, 64, 64, 1, 1},  {112, 64, 128, 0, 1}, {112, 128, 128, 1, 1}, {56, 128, 256, 0, 1},
+        {56, 256, 256, 0, 1}, {56, 256, 256, 1, 1}, {28, 256, 512, 0, 1},  {28, 512, 512, 0, 1},
+        {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
+    };
+    for (const auto& d : layers) {
+        hipError_t e = conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)scan_topk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)scan_topk_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)scan_topk_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
+    return e;
+}
+
+}  // namespace frhot

@@ -1,0 +1,214 @@
+"""Python handles over the C ABI: Context (model + embed pipeline) and Gallery.
+
+Thin by design: argument marshalling and error translation only.  All
+arithmetic happens in libfrhot.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EMBED_DIM, FLAG_GAMMA, FLAG_NOFLIP, KEY_ANY, check
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _crop_args(images):
+    n = len(images)
+    arrs = []
+    for im in images:
+        im = np.asarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError("crops must be uint8 arrays of shape [h, w, 3] (BGR)")
+        if im.strides[2] != 1 or im.strides[1] != 3 or im.strides[0] < 3 * im.shape[1]:
+            im = np.ascontiguousarray(im)
+        arrs.append(im)
+    ptrs = (C.POINTER(C.c_uint8) * n)(*[_ptr(a, C.c_uint8) for a in arrs])
+    hw = np.asarray([(a.shape[0], a.shape[1]) for a in arrs], dtype=np.int32).reshape(n, 2)
+    strides = np.asarray([a.strides[0] for a in arrs], dtype=np.int32)
+    return arrs, ptrs, hw, strides
+
+
+class Context:
+    """One GPU, one stream, one loaded model (frhot_ctx)."""
+
+    def __init__(self, device: int = 0, max_batch: int = 256, stream: int | None = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.frhot_ctx_create(device, C.c_void_p(stream or 0), max_batch, C.byref(self._h)))
+        self.device = device
+        self.max_batch = max_batch
+        self._blob = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.frhot_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(self._lib.frhot_ctx_sync(self._h))
+
+    def load_model(self, blob: np.ndarray, input_scale: float = 1.0 / 16.0):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.frhot_model_load(self._h, C.c_void_p(blob.ctypes.data), blob.size, input_scale))
+
+    @staticmethod
+    def flags(gamma: bool = False, flip: bool = True) -> int:
+        return (FLAG_GAMMA if gamma else 0) | (0 if flip else FLAG_NOFLIP)
+
+    def embed(self, images, gamma: bool = False, flip: bool = True) -> np.ndarray:
+        """uint8 BGR crops -> float32 [n, 4096] unit-norm descriptors (host in, host out)."""
+        n = len(images)
+        out = np.empty((n, EMBED_DIM), dtype=np.float32)
+        for lo in range(0, n, self.max_batch):
+            chunk = images[lo:lo + self.max_batch]
+            arrs, ptrs, hw, strides = _crop_args(chunk)
+            sub = out[lo:lo + len(chunk)]
+            check(self._lib.frhot_embed(self._h, ptrs, _ptr(hw, C.c_int32), _ptr(strides, C.c_int32), len(chunk),
+                                        self.flags(gamma, flip), _ptr(sub, C.c_float)))
+        return out
+
+    def embed_dev(self, crops_dev: int, offsets: np.ndarray, hw: np.ndarray, strides: np.ndarray, flags: int,
+                  out_f32_dev: int | None, out_q_f16_dev: int | None, dq: int = EMBED_DIM):
+        """Device-pointer form; enqueues only."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        hw = np.ascontiguousarray(hw, dtype=np.int32)
+        strides = np.ascontiguousarray(strides, dtype=np.int32)
+        check(self._lib.frhot_embed_dev(self._h, C.c_void_p(crops_dev), _ptr(offsets, C.c_int64),
+                                        _ptr(hw, C.c_int32), _ptr(strides, C.c_int32), len(offsets), flags,
+                                        C.c_void_p(out_f32_dev or 0), C.c_void_p(out_q_f16_dev or 0), dq))
+
+    def debug_read(self, stage: int, n: int) -> np.ndarray:
+        if stage == 0:
+            out = np.empty((n, 224, 224, 3), dtype=np.uint8)
+        elif stage == 1:
+            out = np.empty((n, 226, 226, 4), dtype=np.float16)
+        elif 10 <= stage < 23:
+            from .weights import LAYERS
+            pooled = {1, 3, 6, 9, 12}
+            hw = [224, 224, 112, 112, 56, 56, 56, 28, 28, 28, 14, 14, 14][stage - 10]
+            ho = hw // 2 if (stage - 10) in pooled else hw
+            p = ho + (0 if stage == 22 else 2)
+            out = np.empty((n, p, p, LAYERS[stage - 10][4]), dtype=np.float16)
+        elif stage == 30:
+            out = np.empty((n, EMBED_DIM), dtype=np.float16)
+        else:
+            raise ValueError("unknown stage")
+        check(self._lib.frhot_debug_read(self._h, stage, n, C.c_void_p(out.ctypes.data), out.nbytes))
+        return out
+
+    def timing(self, enable: bool = True):
+        check(self._lib.frhot_ctx_timing(self._h, 1 if enable else 0))
+
+    def stage_ms(self) -> dict:
+        ms = np.zeros(5, dtype=np.float32)
+        check(self._lib.frhot_ctx_stage_ms(self._h, _ptr(ms, C.c_float)))
+        return dict(zip(("preprocess", "conv", "fc", "scan", "merge"), (float(x) for x in ms)))
+
+    def merge_topk_dev(self, scores_dev: int, rows_dev: int, p: int, bq: int, k: int, out_s_dev: int, out_r_dev: int):
+        check(self._lib.frhot_merge_topk_dev(self._h, C.c_void_p(scores_dev), C.c_void_p(rows_dev), p, bq, k,
+                                             C.c_void_p(out_s_dev), C.c_void_p(out_r_dev)))
+
+    def recognise(self, gallery: "Gallery", images, qkeys=None, k: int = 5, gamma: bool = False, flip: bool = True,
+                  want_embeddings: bool = False):
+        """Fused embed -> search.  Returns (scores [n,k], rows [n,k], embeddings or None)."""
+        n = len(images)
+        if n > self.max_batch:
+            raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
+        arrs, ptrs, hw, strides = _crop_args(images)
+        scores = np.empty((n, k), dtype=np.float32)
+        rows = np.empty((n, k), dtype=np.int64)
+        emb = np.empty((n, EMBED_DIM), dtype=np.float32) if want_embeddings else None
+        qk = None if qkeys is None else np.ascontiguousarray(qkeys, dtype=np.int32)
+        check(self._lib.frhot_recognise(
+            self._h, gallery.handle, ptrs, _ptr(hw, C.c_int32), _ptr(strides, C.c_int32),
+            _ptr(qk, C.c_int32) if qk is not None else None, n, self.flags(gamma, flip), k,
+            _ptr(emb, C.c_float) if emb is not None else None, _ptr(scores, C.c_float), _ptr(rows, C.c_int64)))
+        return scores, rows, emb
+
+
+class Gallery:
+    """Device-resident [capacity, D] fp16 unit rows + int32 keys (frhot_gallery)."""
+
+    def __init__(self, ctx: Context, dim: int, capacity: int):
+        self._lib = ctx._lib
+        self.ctx = ctx
+        self.dim = dim
+        self.capacity = capacity
+        self._h = C.c_void_p()
+        check(self._lib.frhot_gallery_create(ctx.handle, dim, capacity, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and self.ctx.handle.value:
+            self._lib.frhot_gallery_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def rows(self) -> int:
+        return int(self._lib.frhot_gallery_rows(self._h))
+
+    def upsert(self, vecs: np.ndarray, keys, rows):
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32).reshape(-1, self.dim)
+        n = vecs.shape[0]
+        keys = np.ascontiguousarray(np.broadcast_to(np.asarray(keys, dtype=np.int32), (n,)))
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(n)
+        check(self._lib.frhot_gallery_upsert(self._h, _ptr(vecs, C.c_float), _ptr(keys, C.c_int32),
+                                             _ptr(rows, C.c_int64), n))
+
+    def tombstone(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        check(self._lib.frhot_gallery_tombstone(self._h, _ptr(rows, C.c_int64), rows.size))
+
+    def fill_synthetic(self, seed: int, row0: int, n: int, nkeys: int = 0, dup_every: int = 0):
+        check(self._lib.frhot_gallery_fill_synthetic(self._h, seed, row0, n, nkeys, dup_every))
+
+    def read(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty((rows.size, self.dim), dtype=np.float16)
+        keys = np.empty(rows.size, dtype=np.int32)
+        check(self._lib.frhot_gallery_read(self._h, _ptr(rows, C.c_int64), rows.size, C.c_void_p(out.ctypes.data),
+                                           _ptr(keys, C.c_int32)))
+        return out, keys
+
+    def search(self, q: np.ndarray, qkeys=None, k: int = 5):
+        """float32 queries [Bq, D] (host) -> (scores [Bq,k] f32 descending, rows [Bq,k] i64, -1 = none)."""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.dim)
+        bq = q.shape[0]
+        qk = None if qkeys is None else np.ascontiguousarray(np.broadcast_to(np.asarray(qkeys, np.int32), (bq,)))
+        scores = np.empty((bq, k), dtype=np.float32)
+        rows = np.empty((bq, k), dtype=np.int64)
+        check(self._lib.frhot_search(self._h, _ptr(q, C.c_float), _ptr(qk, C.c_int32) if qk is not None else None,
+                                     bq, k, _ptr(scores, C.c_float), _ptr(rows, C.c_int64)))
+        return scores, rows
+
+    def search_dev(self, q_f16_dev: int, qkeys_dev: int | None, bq: int, k: int, scores_dev: int, rows_dev: int,
+                   row_base: int = 0):
+        check(self._lib.frhot_search_dev(self._h, C.c_void_p(q_f16_dev), C.c_void_p(qkeys_dev or 0), bq, k,
+                                         C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
+
+
+__all__ = ["Context", "Gallery", "EMBED_DIM", "KEY_ANY"]

@@ -1,0 +1,205 @@
+/*
+ * frhot.h — C ABI of libfrhot.so, the MI355X (gfx950) recognition hot path.
+ *
+ * The library replaces three things the reference reaches through Python
+ * packages and HTTP hops: the DeepFace "VGG-Face" descriptor, the Qdrant exact
+ * cosine search, and the glue between them.  Every entry point below names the
+ * reference interface it stands in for (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns
+ *     FRHOT_OK (0) or a negative FRHOT_E* code, and frhot_last_error() gives the
+ *     calling thread's message for the last failure;
+ *   - "host" pointers are ordinary process memory owned by the caller; "dev"
+ *     pointers are device (HBM) addresses on the context's GPU, owned by the
+ *     caller (for example torch tensors); the library owns what it allocates
+ *     behind the opaque handles;
+ *   - a context is bound to one GPU and one HIP stream; calls on one context
+ *     are serialised by an internal mutex, so callers may share it between
+ *     threads; *_dev calls only enqueue work on the stream and do not wait.
+ */
+#ifndef FRHOT_H
+#define FRHOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRHOT_OK            0
+#define FRHOT_EINVAL       (-1)   /* bad argument / shape */
+#define FRHOT_EHIP         (-2)   /* a HIP runtime call failed */
+#define FRHOT_ESTATE       (-3)   /* call order (model not loaded, ...) */
+#define FRHOT_ECAPACITY    (-4)   /* batch / gallery capacity exceeded */
+
+#define FRHOT_EMBED_DIM     4096
+#define FRHOT_INPUT_SIZE    224
+
+/* preprocessing flags of frhot_embed* */
+#define FRHOT_FLAG_GAMMA    1u    /* apply the gamma-1.5 LUT first (app/src/utils/legacy.py:106-110) */
+#define FRHOT_FLAG_NOFLIP   2u    /* skip the channel reverse DeepFace.represent performs */
+
+/* query keys */
+#define FRHOT_KEY_ANY       (-2)  /* query matches every live row */
+#define FRHOT_KEY_DEAD      (-1)  /* row key of a tombstoned row */
+
+typedef struct frhot_ctx frhot_ctx;
+typedef struct frhot_gallery frhot_gallery;
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* frhot_last_error(void);
+
+/* Library build information (arch, kernel set); static string. */
+const char* frhot_version(void);
+
+/*
+ * Context = one GPU + one stream + the model + activation workspace.
+ * `stream` is a hipStream_t to enqueue on (NULL: the library creates its own).
+ * `max_batch` bounds the crops one frhot_embed* call may carry.
+ * Replaces: the per-process DeepFace model singleton warmed up in
+ * app/src/api/app.py:112-118.
+ */
+int frhot_ctx_create(int device_id, void* stream, int max_batch, frhot_ctx** out);
+int frhot_ctx_destroy(frhot_ctx* ctx);
+int frhot_ctx_sync(frhot_ctx* ctx);
+
+/*
+ * Load VGG-Face weights from the library's flat blob format (see
+ * frhot/weights.py): 13 conv tensors [Cout,3,3,Cin], fc6 [4096,7,7,512],
+ * fc7 [4096,4096], all fp16, and fp32 biases.  `input_scale` (a power of two,
+ * e.g. 1/16) multiplies the network input and every bias so that activations
+ * stay inside fp16 range; it cancels in the final L2 normalisation.
+ * Replaces: the weight download + Keras model build behind
+ * DeepFace.represent(model_name="VGG-Face") (app/src/utils/legacy.py:52-54,
+ * app/Dockerfile:79-81).
+ */
+int frhot_model_load(frhot_ctx* ctx, const void* blob, size_t nbytes, float input_scale);
+
+/*
+ * Embed B crops given as host buffers: crops[i] points at an uint8 BGR HWC
+ * image of hw[2i] rows x hw[2i+1] columns whose rows are strides[i] bytes apart.
+ * Writes B unit-norm float32 descriptors of 4096 components to `out` (host).
+ * Replaces: get_embedding(imgf, imgf_real)[0] (app/src/utils/legacy.py:48-59,74),
+ * i.e. DeepFace.represent(detector_backend="skip", normalization="VGGFace2")
+ * including its resize / pad / mean subtraction and the final L2 norm.
+ */
+int frhot_embed(frhot_ctx* ctx, const uint8_t* const* crops, const int32_t* hw,
+                const int32_t* strides, int B, unsigned flags, float* out);
+
+/*
+ * Same computation with the pixels already in HBM: `crops_dev` is one device
+ * buffer, image i starts at byte offsets[i] (host array) with geometry hw /
+ * strides (host arrays).  Outputs are device pointers (either may be NULL):
+ * `out_f32_dev` [B,4096] float32 unit-norm; `out_q_f16_dev` [B,Dq] fp16 holding
+ * the leading Dq components re-normalised to unit length (Dq == 4096 is the
+ * descriptor itself) — the layout frhot_search_dev takes as queries.
+ * Enqueues on the context stream and returns without waiting.
+ */
+int frhot_embed_dev(frhot_ctx* ctx, const void* crops_dev, const int64_t* offsets,
+                    const int32_t* hw, const int32_t* strides, int B, unsigned flags,
+                    void* out_f32_dev, void* out_q_f16_dev, int Dq);
+
+/*
+ * Stage outputs for tests and profiling (device -> host copies, waits):
+ * stage 0: uint8 [B,224,224,3] resized+padded image (before float conversion);
+ * stage 1: fp16 [B,226,226,4] network input (halo and 4th channel zero);
+ * stage 10+l (l = 0..12): fp16 output of conv layer l (conv1_1 .. conv5_3, after its
+ *   pooling where it has one), [B,P,P,C] with a one-pixel zero halo except l = 12;
+ * stage 30: fp16 [B,4096] fc6 output (input-scaled like every activation).
+ */
+int frhot_debug_read(frhot_ctx* ctx, int stage, int B, void* host_out, size_t nbytes);
+
+/*
+ * Gallery = device-resident [capacity, D] fp16 unit rows + int32 key per row.
+ * A key stands for the reference's collection name f"{store_id}_Employees" /
+ * f"{store_id}_Customers" (app/src/services/face_service.py:355-360), which
+ * also subsumes the store_id payload filter of qdrant_database_FE/app.py:320-327.
+ * Replaces: create_collection (qdrant_database_FE/app.py:108-128).
+ */
+int frhot_gallery_create(frhot_ctx* ctx, int D, int64_t capacity, frhot_gallery** out);
+int frhot_gallery_destroy(frhot_gallery* g);
+
+/*
+ * Write n rows: vecs [n,D] float32 (host; normalised to unit length inside, a
+ * zero row is stored as zeros), keys[n], destination row index rows[n].
+ * Replaces: client.upsert of qdrant_database_FE/app.py:289-293 (Qdrant
+ * normalises COSINE vectors at upsert).
+ */
+int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* keys,
+                         const int64_t* rows, int n);
+
+/* Mark rows deleted (key := FRHOT_KEY_DEAD).  Replaces: client.delete of
+ * qdrant_database_FE/app.py:237-240,423-435. */
+int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n);
+
+/*
+ * Fill rows [row0, row0+n) with the library's deterministic synthetic gallery
+ * (integer hash -> unit fp16 rows; `nkeys` > 0 assigns key = hash % nkeys, else
+ * key 0) and plant every `dup_every`-th row as an exact duplicate of its
+ * predecessor (0: none).  Benchmark / test data only; no reference counterpart.
+ */
+int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, int64_t n,
+                                 int nkeys, int dup_every);
+
+/* Copy n stored rows back as fp16 [n,D] plus their keys (host buffers). */
+int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f16, int32_t* out_keys);
+
+/* Number of rows the scan covers: 1 + the highest row ever written. */
+int64_t frhot_gallery_rows(frhot_gallery* g);
+
+/*
+ * Exact cosine top-k of Bq queries against every live row whose key matches
+ * qkeys[i] (FRHOT_KEY_ANY: all live rows; qkeys NULL: ANY for all).  `q` is
+ * [Bq,D] float32 on the host (normalised inside).  scores [Bq,k] float32
+ * descending, rows [Bq,k] int64 (-1 and score -inf where fewer than k rows
+ * match).  Ties in score are ordered by ascending row.
+ * Replaces: client.search(exact=True, limit=5, store_id filter) of
+ * qdrant_database_FE/app.py:316-337.
+ */
+int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq, int k,
+                 float* scores, int64_t* rows);
+
+/*
+ * Device-pointer form: q_f16_dev [Bq,D] fp16 unit rows, qkeys_dev [Bq] int32 or
+ * NULL, outputs scores_dev [Bq,k] float32 and rows_dev [Bq,k] int64 with
+ * `row_base` added to every valid row (the shard's first global row).
+ * Enqueues on the context stream and returns without waiting.
+ */
+int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev,
+                     int Bq, int k, void* scores_dev, void* rows_dev, int64_t row_base);
+
+/*
+ * Merge P per-shard answers (the all-gathered outputs of frhot_search_dev laid
+ * out [P,Bq,k]) into the global top-k [Bq,k].  All pointers are device memory.
+ * Replaces: nothing in the reference (one Qdrant node); it is the reduce step
+ * of the row-sharded scan.
+ */
+int frhot_merge_topk_dev(frhot_ctx* ctx, const void* scores_dev, const void* rows_dev,
+                         int P, int Bq, int k, void* out_scores_dev, void* out_rows_dev);
+
+/*
+ * Fused embed -> search on one GPU: B host crops, qkeys[B] (or NULL), top-k
+ * against gallery g of dimension D (4096, or < 4096 to match on the leading D
+ * components re-normalised).  emb_out may be NULL.
+ * Replaces: get_embedding + DatabaseClient.search_point round trip
+ * (app/src/services/face_service.py:231-233,275-291).
+ */
+int frhot_recognise(frhot_ctx* ctx, frhot_gallery* g, const uint8_t* const* crops,
+                    const int32_t* hw, const int32_t* strides, const int32_t* qkeys, int B,
+                    unsigned flags, int k, float* emb_out, float* scores, int64_t* rows);
+
+/*
+ * Time (milliseconds, HIP events on the context stream) of the kernels the last
+ * frhot_embed* / frhot_search* call launched, by stage: 0 preprocess, 1 conv
+ * stack, 2 fc6+fc7+norm, 3 gallery scan, 4 top-k merge.  Valid only after
+ * frhot_ctx_timing(ctx, 1) enabled event recording; waits for the stream.
+ */
+int frhot_ctx_timing(frhot_ctx* ctx, int enable);
+int frhot_ctx_stage_ms(frhot_ctx* ctx, float* ms5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRHOT_H */

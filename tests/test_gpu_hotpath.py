@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import cosine_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _crops():
+    from frhot import synth
+    imgs = synth.crops(seed=11, n=5, lo=96, hi=300)
+    rng = np.random.default_rng(5)
+    imgs.append(synth.crop(rng, 448, 448))      # exact 2x downscale -> area path
+    imgs.append(synth.crop(rng, 224, 224))      # identity resize
+    imgs.append(synth.crop(rng, 130, 517))      # wide: vertical padding
+    imgs.append(synth.crop(rng, 601, 97))       # tall: horizontal padding, truncated dsize
+    imgs.append(np.ones((64, 80, 3), np.uint8)) # max <= 1: DeepFace skips the /255
+    imgs.append(np.zeros((50, 50, 3), np.uint8))
+    return imgs
+
+
+@pytest.mark.parametrize("gamma,flip", [(False, True), (True, True), (True, False)])
+def test_preprocess_exact(gpu_ctx, gamma, flip):
+    from oracle import preprocess as op
+    imgs = _crops()
+    gpu_ctx.embed(imgs, gamma=gamma, flip=flip)
+    u8 = gpu_ctx.debug_read(0, len(imgs))
+    x0 = gpu_ctx.debug_read(1, len(imgs))
+    for i, im in enumerate(imgs):
+        want_u8 = op.preprocess_u8(im, apply_gamma=gamma, flip=flip)
+        assert np.array_equal(u8[i], want_u8), f"crop {i} {im.shape}: resized bytes differ"
+        want = (op.preprocess(im, apply_gamma=gamma, flip=flip) * np.float32(1.0 / 16.0)).astype(np.float16)
+        assert np.array_equal(x0[i, 1:225, 1:225, :3], want), f"crop {i}: network input differs"
+        assert not x0[i, 0].any() and not x0[i, 225].any() and not x0[i, :, 0].any() and not x0[i, :, 225].any()
+        assert not x0[i, :, :, 3].any()
+
+
+def _oracle_layers(x_nhwc, weights):
+    """Per-layer float32 activations (NHWC, after pooling where present) + fc6, fc7."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.vggface import CONV_LAYERS
+    outs = []
+    x = torch.from_numpy(x_nhwc).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        for name, _ci, _co, pool in CONV_LAYERS:
+            w = torch.from_numpy(weights[name + ".w"]).permute(0, 3, 1, 2)
+            x = F.relu(F.conv2d(x, w, torch.from_numpy(weights[name + ".b"]), padding=1))
+            if pool:
+                x = F.max_pool2d(x, 2, 2)
+            outs.append(x.permute(0, 2, 3, 1).numpy())
+        w6 = torch.from_numpy(weights["fc6.w"]).permute(0, 3, 1, 2)
+        x = F.relu(F.conv2d(x, w6, torch.from_numpy(weights["fc6.b"])))
+        outs.append(x.flatten(1).numpy())
+    return outs
+
+
+def test_layers_match_oracle(gpu_ctx, weights_q):
+    """Every conv layer and fc6, against the oracle run on the same fp16-rounded weights."""
+    from frhot import synth
+    from oracle import preprocess as op
+    imgs = synth.crops(seed=3, n=2, lo=150, hi=260)
+    gpu_ctx.embed(imgs)
+    x = np.stack([op.preprocess(im) for im in imgs])
+    want = _oracle_layers(x, weights_q)
+    s = 1.0 / 16.0
+    for l in range(13):
+        got = gpu_ctx.debug_read(10 + l, len(imgs)).astype(np.float32) / s
+        if l < 12:
+            assert not got[:, 0].any() and not got[:, -1].any() and not got[:, :, 0].any() and not got[:, :, -1].any(), \
+                f"layer {l}: halo not zero"
+            got = got[:, 1:-1, 1:-1]
+        ref = want[l]
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+        scale = np.abs(ref).max()
+        assert err <= 4e-3 * scale, f"conv layer {l}: max err {err} vs scale {scale}"
+    got6 = gpu_ctx.debug_read(30, len(imgs)).astype(np.float32) / s
+    assert np.abs(got6 - want[13]).max() <= 4e-3 * np.abs(want[13]).max()
+
+
+def test_embedding_cosine(gpu_ctx, weights_f32, weights_q):
+    """cosine(GPU descriptor, oracle descriptor) >= 0.9999 per face (tolerance of the north star)."""
+    from frhot import synth
+    from oracle import preprocess as op, vggface
+    imgs = synth.crops(seed=21, n=6, lo=112, hi=448)
+    got = gpu_ctx.embed(imgs, gamma=True)
+    assert got.shape == (6, 4096) and got.dtype == np.float32
+    assert np.allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=1e-5)
+    assert (got >= 0).all()
+    x = np.stack([op.preprocess(im, apply_gamma=True) for im in imgs])
+    ref32 = vggface.embed(x, weights_f32)      # the reference's precision: float32 weights
+    refq = vggface.embed(x, weights_q)         # same fp16-rounded weights as the GPU
+    c32 = cosine_rows(got, ref32)
+    cq = cosine_rows(got, refq)
+    assert cq.min() >= 0.9999, f"cosine vs same-weights oracle {cq}"
+    assert c32.min() >= 0.9999, f"cosine vs float32-weights oracle {c32}"
+
+
+def test_embed_batch_invariance(gpu_ctx):
+    """A crop's descriptor does not depend on its batch neighbours or position."""
+    from frhot import synth
+    imgs = synth.crops(seed=8, n=5, lo=100, hi=200)
+    a = gpu_ctx.embed(imgs)
+    b = gpu_ctx.embed(imgs[::-1])[::-1]
+    c = gpu_ctx.embed([imgs[2]])
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[2:3], c)
+
+
+def _check_topk(got_s, got_r, ref_s, ref_r, full_scores=None, tol=1e-4):
+    """Identical id lists except inside score ties within tol."""
+    assert got_r.shape == ref_r.shape
+    for i in range(ref_r.shape[0]):
+        if np.array_equal(got_r[i], ref_r[i]):
+            continue
+        for j in range(ref_r.shape[1]):
+            if got_r[i, j] == ref_r[i, j]:
+                continue
+            assert (got_r[i, j] >= 0) == (ref_r[i, j] >= 0), f"query {i} slot {j}: presence differs"
+            # a differing slot must hold a row whose oracle score ties the oracle's slot score
+            assert full_scores is not None
+            assert abs(full_scores[i, got_r[i, j]] - ref_s[i, j]) <= tol, \
+                f"query {i} slot {j}: row {got_r[i, j]} vs {ref_r[i, j]} is not a tie"
+    ok = np.isfinite(ref_s)
+    assert np.abs(got_s[ok] - ref_s[ok]).max() <= tol
+
+
+@pytest.mark.parametrize("n,d,bq,k", [(5000, 512, 64, 10), (3001, 4096, 7, 5), (777, 512, 130, 5), (40, 512, 3, 5),
+                                      (3, 64, 2, 5)])
+def test_search_matches_oracle(gpu_ctx, n, d, bq, k):
+    from frhot import synth
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    g = synth.unit_gallery(seed=n, n=n, d=d, sparse=(d == 4096))
+    g[n // 2] = g[n // 3]                                    # exact duplicate -> documented tie
+    rng = np.random.default_rng(n + 1)
+    targets = rng.integers(0, n, size=bq)
+    q = synth.planted_queries(rng, g[targets], 0.8)
+    gal = Gallery(gpu_ctx, d, n + 10)
+    gal.upsert(g, 0, np.arange(n))
+    got_s, got_r = gal.search(q, None, k)
+    ref_s, ref_r = osr.cosine_topk(q, g, k, gallery_dtype=np.float16)
+    full = osr.unit_rows(q).astype(np.float16).astype(np.float32) @ osr.unit_rows(g).astype(np.float16).astype(np.float32).T
+    _check_topk(got_s, got_r, ref_s, ref_r, full, tol=2e-5)
+    # against the reference's float32 precision: ties within 1e-4
+    ref_s32, ref_r32 = osr.cosine_topk(q, g, k)
+    full32 = osr.unit_rows(q) @ osr.unit_rows(g).T
+    _check_topk(got_s, got_r, ref_s32, ref_r32, full32, tol=1e-4)
+    if n >= k:
+        assert (got_r[:, 0] == targets).mean() >= 0.9 or d < 256
+    gal.close()
+
+
+def test_search_key_filter_and_tombstones(gpu_ctx):
+    from frhot import synth
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    n, d, bq, k = 4000, 512, 50, 5
+    g = synth.unit_gallery(seed=77, n=n, d=d)
+    rng = np.random.default_rng(78)
+    keys = rng.integers(0, 6, size=n).astype(np.int32)
+    targets = rng.integers(0, n, size=bq)
+    q = synth.planted_queries(rng, g[targets], 0.8)
+    qkeys = keys[targets].copy()
+    qkeys[:5] = (qkeys[:5] + 1) % 6          # wrong collection: the planted row must not be found
+    qkeys[5:8] = -2                          # ANY
+    qkeys[8] = 99                            # a key nobody has -> empty answer
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, keys, np.arange(n))
+    dead = targets[10:14]
+    gal.tombstone(dead)
+    keys_ref = keys.copy()
+    keys_ref[dead] = -1
+    got_s, got_r = gal.search(q, qkeys, k)
+    ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys_ref, qkeys=qkeys, gallery_dtype=np.float16)
+    full = osr.unit_rows(q).astype(np.float16).astype(np.float32) @ osr.unit_rows(g).astype(np.float16).astype(np.float32).T
+    _check_topk(got_s, got_r, ref_s, ref_r, full, tol=2e-5)
+    assert (got_r[8] == -1).all() and np.isneginf(got_s[8]).all()
+    assert not np.isin(got_r[10:14, 0], dead).any()
+    for i in range(5):
+        assert targets[i] not in got_r[i]
+    gal.close()
+
+
+def test_synthetic_fill_bit_exact(gpu_ctx):
+    from frhot.engine import Gallery
+    from oracle import synth_gallery as sg
+    d, n = 512, 3000
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=0xFACE0002, row0=0, n=n, nkeys=7, dup_every=100)
+    rows = np.concatenate([np.arange(0, 300), np.arange(n - 200, n)])
+    got, got_keys = gal.read(rows)
+    want = sg.rows_f16(0xFACE0002, rows, d, dup_every=100)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    assert np.array_equal(got_keys, sg.keys(0xFACE0002, rows, 7, dup_every=100))
+    assert np.array_equal(got[99].view(np.uint16), got[98].view(np.uint16))   # planted duplicate
+    gal.close()
+
+
+def test_recognise_fused_equals_two_calls(gpu_ctx):
+    from frhot import synth
+    from frhot.engine import Gallery
+    imgs = synth.crops(seed=31, n=4, lo=120, hi=240)
+    emb = gpu_ctx.embed(imgs)
+    rng = np.random.default_rng(1)
+    g = synth.unit_gallery(seed=32, n=600, d=4096, sparse=True)
+    g[17] = emb[1]
+    g[333] = emb[3]
+    gal = Gallery(gpu_ctx, 4096, 600)
+    gal.upsert(g, 0, np.arange(600))
+    s1, r1 = gal.search(emb, None, 5)
+    s2, r2, e2 = gpu_ctx.recognise(gal, imgs, None, 5, want_embeddings=True)
+    assert np.array_equal(e2, emb)
+    assert np.array_equal(r1, r2)
+    assert np.abs(s1 - s2).max() <= 2e-3      # fp16 query rounding differs (f32->unit->f16 vs fused)
+    assert r2[1, 0] == 17 and r2[3, 0] == 333 and s2[1, 0] > 0.999
+    gal.close()
+
+
+def test_errors_are_reported(gpu_ctx):
+    from frhot import FrhotError
+    from frhot.engine import Gallery
+    with pytest.raises(FrhotError):
+        gpu_ctx.embed([np.zeros((10, 4000, 3), np.uint8)])          # resizes to zero rows
+    with pytest.raises(FrhotError):
+        Gallery(gpu_ctx, 100, 10)                                    # D not a multiple of 64
+    gal = Gallery(gpu_ctx, 64, 10)
+    with pytest.raises(FrhotError):
+        gal.upsert(np.ones((1, 64), np.float32), 0, [10])            # row beyond capacity
+    with pytest.raises(FrhotError):
+        gal.search(np.ones((1, 64), np.float32), None, 17)           # k too large
+    s, r = gal.search(np.ones((2, 64), np.float32), None, 5)         # empty gallery
+    assert (r == -1).all() and np.isneginf(s).all()
+    gal.close()
