@@ -85,7 +85,7 @@ struct frhot_ctx {
     bool model = false;
     float input_scale = 1.0f;
     // weights
-    void* w[kNumConv] = {};      // fp16 [Cout][9*Cin]; w[0] is the packed [64][48] conv1_1 matrix
+    void* w[kNumConv] = {};      // fp16 [Cout][9*Cin]; w[0] is the packed [64][64] conv1_1 matrix
     float* bias[kNumConv] = {};
     void *w6 = nullptr, *w7 = nullptr;
     float *b6 = nullptr, *b7 = nullptr;
@@ -398,12 +398,12 @@ int frhot_model_load(frhot_ctx* c, const void* blob_v, size_t nbytes, float inpu
         if (!e) return FRHOT_EINVAL;
         int rc;
         if (l == 0) {
-            // [64][3][3][3] -> [64][48], k = tap*4 + c, zero elsewhere
-            std::vector<uint16_t> p(64 * 48, 0);
+            // [64][3][3][3] -> [64][64], k = tap*4 + c, zero elsewhere
+            std::vector<uint16_t> p(64 * 64, 0);
             const uint16_t* src = (const uint16_t*)(blob + e->offset);
             for (int n = 0; n < 64; ++n)
                 for (int t = 0; t < 9; ++t)
-                    for (int ch = 0; ch < 3; ++ch) p[n * 48 + t * 4 + ch] = src[(n * 9 + t) * 3 + ch];
+                    for (int ch = 0; ch < 3; ++ch) p[n * 64 + t * 4 + ch] = src[(n * 9 + t) * 3 + ch];
             rc = upload(&c->w[0], p.data(), p.size() * 2);
         } else {
             rc = upload(&c->w[l], blob + e->offset, e->nbytes);

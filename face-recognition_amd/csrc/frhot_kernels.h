@@ -29,7 +29,7 @@ hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const ui
                             int flip, uint8_t* out_u8, int* out_max, int B, hipStream_t s);
 hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale,
                                  void* x0_f16, int B, hipStream_t s);
-hipError_t launch_conv1_1(const void* x0, const void* w48, const float* bias, void* y,
+hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y,
                           int B, hipStream_t s);
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias,
                           void* y, int B, hipStream_t s);

@@ -213,24 +213,23 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const half_t* __rest
 
 // ------------------------------------------------------------ conv1_1 ------
 // 3 -> 64 channels.  Input fp16 [B,226,226,4] (4th channel zero), weights
-// fp16 [64][48] with k = tap*4 + c for k < 36 and zeros after.  K is covered by one
-// 16x16x32 MFMA (taps 0..7) and one 16x16x16 MFMA (tap 8 + zero padding).
+// fp16 [64][64] with k = tap*4 + c for k < 36 and zeros after.  K is covered by two
+// 16x16x32 MFMAs (taps 0..7, then tap 8 + zero padding).
 // Each wave turns 16 consecutive pixels of a row into 16 x 64 outputs per step.
 __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__ x0,
-                                                      const half_t* __restrict__ w48,
+                                                      const half_t* __restrict__ w64,
                                                       const float* __restrict__ bias,
                                                       half_t* __restrict__ y, int ntiles) {
     constexpr int P = 226, T = 14;  // padded width, 16-pixel tiles per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    half8 a32[4];
-    half4 a16[4];
+    half8 a0[4], a1[4];
     float4v bv[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-        const half_t* wr = w48 + (ct * 16 + l15) * 48;
-        a32[ct] = *(const half8*)(wr + 8 * g);
-        a16[ct] = *(const half4*)(wr + 32 + 4 * g);
+        const half_t* wr = w64 + (ct * 16 + l15) * 64;
+        a0[ct] = *(const half8*)(wr + 8 * g);
+        a1[ct] = *(const half8*)(wr + 32 + 8 * g);
         bv[ct] = *(const float4v*)(bias + ct * 16 + g * 4);
     }
     const int t0 = 2 * g, t1 = 2 * g + 1;
@@ -244,13 +243,15 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__
         const half4 v0 = *(const half4*)(src + off0);
         const half4 v1 = *(const half4*)(src + off1);
         const half4 v8 = *(const half4*)(src + off8);
-        const half8 bf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const half_t z = (half_t)0.f;
+        const half8 bf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const half8 bf1 = {v8[0], v8[1], v8[2], v8[3], z, z, z, z};   // weights are zero beyond k = 35
         half_t* dst = y + (((long)b * P + py + 1) * P + px + 1) * 64 + g * 4;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             float4v acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[ct], bf, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a16[ct], v8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ct], bf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ct], bf1, acc, 0, 0, 0);
             half4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(acc[j] + bv[ct][j], 0.f);
@@ -804,12 +805,12 @@ hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, 
     return conv_dispatch(d, x, w, bias, y, B, s, false);
 }
 
-hipError_t launch_conv1_1(const void* x0, const void* w48, const float* bias, void* y, int B, hipStream_t s) {
-    if (B <= 0 || !x0 || !w48 || !bias || !y) return hipErrorInvalidValue;
+hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y, int B, hipStream_t s) {
+    if (B <= 0 || !x0 || !w64 || !bias || !y) return hipErrorInvalidValue;
     const long ntiles = (long)B * 224 * 14;
     if (ntiles > 0x7fffffffL) return hipErrorInvalidValue;
     const int blocks = (int)((ntiles + 3) / 4 < 4096 ? (ntiles + 3) / 4 : 4096);
-    hipLaunchKernelGGL(conv1_1_kernel, dim3(blocks), dim3(256), 0, s, (const half_t*)x0, (const half_t*)w48, bias,
+    hipLaunchKernelGGL(conv1_1_kernel, dim3(blocks), dim3(256), 0, s, (const half_t*)x0, (const half_t*)w64, bias,
                        (half_t*)y, (int)ntiles);
     FR_CHECK_LAUNCH();
     return hipSuccess;
