@@ -105,9 +105,21 @@ struct frhot_ctx {
     int32_t* qkeys_dev = nullptr;
     float* res_s = nullptr; int64_t* res_r = nullptr;  // [B,16]
     std::vector<CropMeta> meta_host;
-    // timing
+    // timing: per stage a ring of (begin, end) event pairs; n[i] counts recorded pairs
     bool timing = false;
-    hipEvent_t ev[6] = {};
+    static constexpr int kRing = 128;
+    hipEvent_t ev_b[5][kRing] = {}, ev_e[5][kRing] = {};
+    long ev_n[5] = {};
+    int stage_begin(int i) {
+        if (!timing) return 0;
+        return hipEventRecord(ev_b[i][ev_n[i] % kRing], stream) == hipSuccess ? 0 : 1;
+    }
+    int stage_end(int i) {
+        if (!timing) return 0;
+        const int rc = hipEventRecord(ev_e[i][ev_n[i] % kRing], stream) == hipSuccess ? 0 : 1;
+        ++ev_n[i];
+        return rc;
+    }
 };
 
 struct frhot_gallery {
@@ -169,23 +181,23 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
     }
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(c->meta_dev, c->meta_host.data(), sizeof(CropMeta) * B, hipMemcpyHostToDevice, s));
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
+    if (c->stage_begin(0)) return fail(FRHOT_EHIP, "event record failed");
     const uint8_t* lut = c->lut_dev + ((flags & FRHOT_FLAG_GAMMA) ? 256 : 0);
     HIP_TRY(launch_resize_u8((const uint8_t*)crops_dev, c->meta_dev, lut, (flags & FRHOT_FLAG_NOFLIP) ? 0 : 1, c->u8,
                              c->img_max, B, s));
     HIP_TRY(launch_normalize_pack(c->u8, c->img_max, c->input_scale, c->x0, B, s));
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
+    if (c->stage_end(0) || c->stage_begin(1)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_conv1_1(c->x0, c->w[0], c->bias[0], c->act[0], B, s));
     for (int l = 1; l < kNumConv; ++l) {
         ConvLayerDesc d{kConv[l].hw, kConv[l].cin, kConv[l].cout, kConv[l].pool, kConv[l].opad};
         HIP_TRY(launch_conv3x3(d, c->act[l - 1], c->w[l], c->bias[l], c->act[l], B, s));
     }
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (c->stage_end(1) || c->stage_begin(2)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_fc_splitk(c->act[kNumConv - 1], c->w6, c->partial, B, kFcN, kFc6K, kFc6Split, s));
     HIP_TRY(launch_fc_reduce_relu(c->partial, c->b6, c->fc6_out, B, kFcN, kFc6Split, s));
     HIP_TRY(launch_fc_splitk(c->fc6_out, c->w7, c->partial, B, kFcN, kFcN, kFc7Split, s));
     HIP_TRY(launch_fc_reduce_relu_l2(c->partial, c->b7, out_f32, out_q, out_q ? Dq : kFcN, B, kFcN, kFc7Split, s));
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], s));
+    if (c->stage_end(2)) return fail(FRHOT_EHIP, "event record failed");
     return FRHOT_OK;
 }
 
@@ -225,14 +237,12 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
     if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
     if (!q16 || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null search arguments");
     hipStream_t s = c->stream;
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[3], s));
     if (g->nrows == 0) {
         // nothing stored: -inf / -1 everywhere, via the final kernel over one empty list
         HIP_TRY(hipMemsetAsync(rows_dev, 0xFF, sizeof(int64_t) * (size_t)Bq * k, s));
         std::vector<float> ninf((size_t)Bq * k, -INFINITY);
         HIP_TRY(hipMemcpyAsync(scores_dev, ninf.data(), sizeof(float) * ninf.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (c->timing) { HIP_TRY(hipEventRecord(c->ev[4], s)); HIP_TRY(hipEventRecord(c->ev[5], s)); }
         return FRHOT_OK;
     }
     const int kl = scan_list_len(k);
@@ -247,10 +257,11 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
         g->part_cap = need;
     }
     int nblk = 0;
+    if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, Bq, k, g->part_s, g->part_r, &nblk, s));
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[4], s));
+    if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_topk_final(g->part_s, g->part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev[5], s));
+    if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
     return FRHOT_OK;
 }
 
@@ -309,7 +320,6 @@ static int ctx_init(frhot_ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->lut_dev, 512));
     HIP_TRY(hipMemcpy(c->lut_dev, lut, 512, hipMemcpyHostToDevice));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FRHOT_OK;
 }
@@ -355,7 +365,11 @@ int frhot_ctx_destroy(frhot_ctx* c) {
         if (c->w[l]) (void)hipFree(c->w[l]);
         if (c->bias[l]) (void)hipFree(c->bias[l]);
     }
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < frhot_ctx::kRing; ++j) {
+            if (c->ev_b[i][j]) (void)hipEventDestroy(c->ev_b[i][j]);
+            if (c->ev_e[i][j]) (void)hipEventDestroy(c->ev_e[i][j]);
+        }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FRHOT_OK;
@@ -665,10 +679,14 @@ int frhot_ctx_timing(frhot_ctx* c, int enable) {
     if (!c) return fail(FRHOT_EINVAL, "ctx is null");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
-    if (enable && !c->timing) {
-        // make every event valid so elapsed-time queries on untouched stages do not fail
-        for (auto& e : c->ev) HIP_TRY(hipEventRecord(e, c->stream));
+    if (enable && !c->ev_b[0][0]) {
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < frhot_ctx::kRing; ++j) {
+                HIP_TRY(hipEventCreate(&c->ev_b[i][j]));
+                HIP_TRY(hipEventCreate(&c->ev_e[i][j]));
+            }
     }
+    for (long& n : c->ev_n) n = 0;
     c->timing = enable != 0;
     return FRHOT_OK;
 }
@@ -680,9 +698,14 @@ int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
     DeviceGuard dg(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 5; ++i) {
-        float ms = 0.f;
-        hipError_t e = hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
-        ms5[i] = (e == hipSuccess && ms >= 0.f) ? ms : 0.f;
+        const long n = c->ev_n[i] < frhot_ctx::kRing ? c->ev_n[i] : frhot_ctx::kRing;
+        double sum = 0.0;
+        for (long j = 0; j < n; ++j) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_b[i][j], c->ev_e[i][j]));
+            sum += ms;
+        }
+        ms5[i] = n > 0 ? (float)(sum / (double)n) : 0.f;
     }
     return FRHOT_OK;
 }

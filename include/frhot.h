@@ -191,10 +191,14 @@ int frhot_recognise(frhot_ctx* ctx, frhot_gallery* g, const uint8_t* const* crop
                     unsigned flags, int k, float* emb_out, float* scores, int64_t* rows);
 
 /*
- * Time (milliseconds, HIP events on the context stream) of the kernels the last
- * frhot_embed* / frhot_search* call launched, by stage: 0 preprocess, 1 conv
- * stack, 2 fc6+fc7+norm, 3 gallery scan, 4 top-k merge.  Valid only after
- * frhot_ctx_timing(ctx, 1) enabled event recording; waits for the stream.
+ * Stage timing with HIP events on the context stream.  frhot_ctx_timing(ctx, 1)
+ * starts (and resets) recording: every later frhot_embed* / frhot_search* call
+ * brackets its stages with event pairs (a ring of the last 128 calls) without
+ * waiting.  frhot_ctx_stage_ms waits for the stream and returns the MEAN
+ * milliseconds per call of each stage since recording started: 0 preprocess,
+ * 1 conv stack, 2 fc6+fc7+norm, 3 gallery scan kernel, 4 top-k final selection.
+ * No reference counterpart beyond the [TIMING] log lines of
+ * app/src/services/face_service.py:229-236,286-296.
  */
 int frhot_ctx_timing(frhot_ctx* ctx, int enable);
 int frhot_ctx_stage_ms(frhot_ctx* ctx, float* ms5);
