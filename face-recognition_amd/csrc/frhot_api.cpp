@@ -126,6 +126,7 @@ struct frhot_gallery {
     frhot_ctx* ctx = nullptr;
     int D = 0;
     int64_t capacity = 0, nrows = 0;
+    bool dense = true;           // every row in [0, nrows) is live: the scan may skip the key test
     void* rows = nullptr;
     int32_t* keys = nullptr;
     float* part_s = nullptr; int64_t* part_r = nullptr; size_t part_cap = 0;
@@ -258,7 +259,9 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
     }
     int nblk = 0;
     if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
-    HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, Bq, k, g->part_s, g->part_r, &nblk, s));
+    const int use_keys = (qkeys_dev != nullptr || !g->dense) ? 1 : 0;
+    HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, use_keys, Bq, k, g->part_s, g->part_r,
+                             &nblk, s));
     if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_topk_final(g->part_s, g->part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
     if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
@@ -488,15 +491,17 @@ int frhot_debug_read(frhot_ctx* c, int stage, int B, void* host_out, size_t nbyt
 int frhot_gallery_create(frhot_ctx* c, int D, int64_t capacity, frhot_gallery** out) {
     if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
     *out = nullptr;
-    if (D <= 0 || D % 64 || D > 8192) return fail(FRHOT_EINVAL, "D %d must be a multiple of 64 up to 8192", D);
+    if (D < 64 || D % 64 || D > 8192) return fail(FRHOT_EINVAL, "D %d must be a multiple of 64 in 64..8192", D);
     if (capacity <= 0 || capacity > 0x7fffff00LL) return fail(FRHOT_EINVAL, "capacity out of range");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
     frhot_gallery* g = new frhot_gallery();
     g->ctx = c; g->D = D; g->capacity = capacity;
-    hipError_t e = hipMalloc(&g->rows, (size_t)capacity * D * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->keys, (size_t)capacity * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(g->keys, 0xFF, (size_t)capacity * 4, c->stream);  // all dead
+    const size_t padded = ((size_t)capacity + 255) & ~(size_t)255;   // the scan reads whole 256-row tiles
+    hipError_t e = hipMalloc(&g->rows, padded * D * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->keys, padded * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(g->rows, 0, padded * D * 2, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(g->keys, 0xFF, padded * 4, c->stream);  // all dead
     if (e != hipSuccess) {
         if (g->rows) (void)hipFree(g->rows);
         if (g->keys) (void)hipFree(g->keys);
@@ -551,6 +556,13 @@ int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* key
     HIP_TRY(hipMemcpyAsync(g->up_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_gallery_upsert(g->up_vecs, g->up_keys, g->up_rows, n, g->rows, g->keys, g->D, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // rows stay dense when the batch only overwrites live rows or appends one contiguous run
+    bool contiguous = true, inside = true;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] != rows[0] + i) contiguous = false;
+        if (rows[i] >= g->nrows) inside = false;
+    }
+    if (!(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
     if (hi + 1 > g->nrows) g->nrows = hi + 1;
     return FRHOT_OK;
 }
@@ -570,6 +582,7 @@ int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(FRHOT_EHIP, "tombstone failed: %s", hipGetErrorString(e));
+    g->dense = false;
     return FRHOT_OK;
 }
 
@@ -582,6 +595,7 @@ int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, 
     DeviceGuard dg(c->device);
     HIP_TRY(launch_gallery_fill(g->rows, g->keys, g->D, seed, row0, n, nkeys, dup_every, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (row0 > g->nrows) g->dense = false;
     if (row0 + n > g->nrows) g->nrows = row0 + n;
     return FRHOT_OK;
 }

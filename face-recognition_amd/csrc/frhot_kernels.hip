@@ -573,135 +573,218 @@ struct TopK {
     }
 };
 
-// Gallery tile = 256 rows (MFMA A operand: rows land in accumulator registers), query
-// tile = 64 queries (B operand: one query per lane & 15).  Waves 2 x 2: each wave owns
-// 128 gallery rows x 32 queries, i.e. two top-k lists per lane.  A block walks gallery
-// tiles blockIdx.x, blockIdx.x + gridDim.x, ... and finally merges its lanes' lists per
-// query into one list of K per (block, query).
-template <int K>
-__global__ __launch_bounds__(256) void scan_topk_kernel(const half_t* __restrict__ gal,
-                                                        const int32_t* __restrict__ gkeys, long nrows, int D,
-                                                        const half_t* __restrict__ q,
-                                                        const int32_t* __restrict__ qkeys, int Bq,
-                                                        float* __restrict__ part_s, long long* __restrict__ part_r) {
-    using Core = GemmCore<256, 64, 2, 2, true>;
+// ------------------------------------------------- 8-wave ring GEMM core ---
+// 512 threads = 8 waves arranged WX x WY over a tile of RX streamed rows by RY resident
+// rows, 64 K-elements per step.  The streamed operand has a ring of three LDS stages
+// (loads issued two steps ahead: HBM latency), the resident operand two stages (one step
+// ahead: L2 latency).  Loads are LDS-DMA, waited for with counted s_waitcnt vmcnt so that
+// the newest stage stays in flight across the step barrier.
+template <int RX, int RY, int WX, int WY, bool X_IS_A>
+struct GemmCore8 {
+    static_assert(WX * WY == 8, "8 waves");
+    static_assert(RX == 256, "the counted waits below assume 4 streamed loads per wave per step");
+    static constexpr int TX = RX / WX, TY = RY / WY;
+    static constexpr int NX = TX / 16, NY = TY / 16;
+    static constexpr int XB = RX * 128, YB = RY * 128;
+    static constexpr int XS = 3, YS = 2;
+    static constexpr int LDS = XS * XB + YS * YB;
+    static constexpr int NPX = RX / 64, NPY = RY / 64;
+    static_assert(RY % 64 == 0 && TX % 16 == 0 && TY % 16 == 0, "tile shape");
+
+    float4v acc[NY][NX];
+
+    FR_DEV void zero() {
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+    FR_DEV static int stage_row(int wave, int lane, int i) { return 8 * (wave + 8 * i) + (lane >> 3); }
+    FR_DEV static int stage_chunk_bytes(int lane) { return (((lane & 7) ^ (lane >> 3)) << 4); }
+
+    FR_DEV static void issue_x(char* xbuf, int wave, const char* const (&xp)[NPX], size_t off) {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) glds16(xp[i] + off, xbuf + (wave + 8 * i) * 1024);
+    }
+    FR_DEV static void issue_y(char* ybuf, int wave, const char* const (&yp)[NPY], size_t off) {
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) glds16(yp[i] + off, ybuf + (wave + 8 * i) * 1024);
+    }
+    // Wait until only the newest streamed stage (NPX loads) is still in flight / nothing is.
+    FR_DEV static void wait_keep_newest() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    FR_DEV static void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+    FR_DEV void compute(const char* xbuf, const char* ybuf, int lane, int wx, int wy) {
+        const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = (((kk * 4 + g0) ^ l7) << 4);
+            half8 fx[NX], fy[NY];
+#pragma unroll
+            for (int y = 0; y < NY; ++y)
+                fy[y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int x = 0; x < NX; ++x)
+                fx[x] = *(const half8*)(xbuf + (wx * TX + x * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int y = 0; y < NY; ++y)
+#pragma unroll
+                for (int x = 0; x < NX; ++x) {
+                    if (X_IS_A)
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], acc[y][x], 0, 0, 0);
+                    else
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[y], fx[x], acc[y][x], 0, 0, 0);
+                }
+        }
+    }
+};
+
+// Gallery scan, 8 waves: gallery tile 256 rows (MFMA A operand), query tile RY in
+// {64,128,256} (B operand, one query per lane & 15).  The 1-D grid holds nb gallery
+// walkers per query tile; walker gb visits gallery tiles gb, gb+nb, ...  Blocks that
+// differ only in their query tile are adjacent on one XCD so that the gallery stream of
+// one is an L2 hit for the others.  The gallery allocation is padded to whole tiles, so
+// loads never leave it; rows >= nrows are masked in the last tile.
+template <int K, int RY, int WX, int WY, bool USE_KEYS>
+__global__ __launch_bounds__(512) void scan_topk8_kernel(const half_t* __restrict__ gal,
+                                                         const int32_t* __restrict__ gkeys, long nrows, int D,
+                                                         const half_t* __restrict__ q,
+                                                         const int32_t* __restrict__ qkeys, int Bq, int nb,
+                                                         float* __restrict__ part_s, long long* __restrict__ part_r) {
+    using Core = GemmCore8<256, RY, WX, WY, true>;
+    constexpr int NY = Core::NY, NX = Core::NX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wx = wave >> 1, wy = wave & 1;
+    char* const xs = smem;
+    char* const ys = smem + Core::XS * Core::XB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = wave / WY, wy = wave % WY;
     const int l15 = lane & 15, g0 = lane >> 4;
-    const int q0 = blockIdx.y * 64;
+    const int qtiles = gridDim.x / nb;
+    const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
+    const int qt = seq % qtiles, gb = (seq / qtiles) * 8 + xcd;
+    const int q0 = qt * RY;
     const int nk = D / 64;
     const long ntiles = (nrows + 255) / 256;
+    const long my_tiles = gb < ntiles ? (ntiles - gb + nb - 1) / nb : 0;
+    const long S = my_tiles * nk;
     const int cb = Core::stage_chunk_bytes(lane);
 
+    const char* xp[Core::NPX];
     const char* yp[Core::NPY];
+#pragma unroll
+    for (int i = 0; i < Core::NPX; ++i)
+        xp[i] = (const char*)gal + (size_t)Core::stage_row(wave, lane, i) * D * 2 + cb;
 #pragma unroll
     for (int i = 0; i < Core::NPY; ++i) {
         int qq = q0 + Core::stage_row(wave, lane, i);
         qq = qq < Bq ? qq : Bq - 1;
         yp[i] = (const char*)q + (size_t)qq * D * 2 + cb;
     }
-    int myq[2], mykey[2];
+    int mykey[NY];
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        myq[y] = q0 + wy * 32 + y * 16 + l15;
-        mykey[y] = (qkeys && myq[y] < Bq) ? qkeys[myq[y]] : -2;
+    for (int y = 0; y < NY; ++y) {
+        const int qq = q0 + wy * Core::TY + y * 16 + l15;
+        mykey[y] = (USE_KEYS && qkeys && qq < Bq) ? qkeys[qq] : -2;
     }
-    TopK<K> top[2];
-    top[0].init(); top[1].init();
+    TopK<K> top[NY];
+#pragma unroll
+    for (int y = 0; y < NY; ++y) top[y].init();
 
     Core core;
-    long tile = blockIdx.x;
-    if (tile < ntiles) {
-        const char* xp[Core::NPX];
-        auto set_rows = [&](long t) {
-#pragma unroll
-            for (int i = 0; i < Core::NPX; ++i) {
-                long rr = t * 256 + Core::stage_row(wave, lane, i);
-                rr = rr < nrows ? rr : nrows - 1;
-                xp[i] = (const char*)gal + (size_t)rr * D * 2 + cb;
-            }
+    core.zero();
+    if (S > 0) {
+        long itile = gb; int iks = 0;   // next streamed step to issue
+        int yks = 0;                    // next resident step to issue
+        auto next_x = [&](int slot) {
+            const size_t off = ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
+            Core::issue_x(xs + slot * Core::XB, wave, xp, off);
+            if (++iks == nk) { iks = 0; itile += nb; }
         };
-        set_rows(tile);
-        core.zero();
-        Core::issue(smem, wave, xp, 0, yp, 0);
-        __syncthreads();
-        int cur = 0, ks = 0;
-        while (true) {
-            // stage the next (tile, k-step), if any
-            const bool last_k = (ks == nk - 1);
-            const long ntile = tile + gridDim.x;
-            const bool more = !last_k || ntile < ntiles;
-            if (more) {
-                if (last_k) {
-                    set_rows(ntile);
-                    Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, 0, yp, 0);
-                } else {
-                    Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, (size_t)(ks + 1) * 128, yp,
-                                (size_t)(ks + 1) * 128);
-                }
-            }
-            core.compute(smem + cur * Core::SB, lane, wx, wy);
-            if (last_k) {
-                // fold this tile's scores into the per-lane lists
-                const long rbase = tile * 256 + wx * 128 + g0 * 4;
+        auto next_y = [&](int slot) {
+            Core::issue_y(ys + slot * Core::YB, wave, yp, (size_t)yks * 128);
+            if (++yks == nk) yks = 0;
+        };
+        next_y(0);
+        next_x(0);
+        if (S > 1) { next_x(1); Core::wait_keep_newest(); } else { Core::wait_all(); }
+        __builtin_amdgcn_s_barrier();
+        int xslot = 0, yslot = 0, ks = 0;
+        long tile = gb;
+        for (long s = 0; s < S; ++s) {
+            if (s + 1 < S) next_y(yslot ^ 1);
+            if (s + 2 < S) next_x(xslot == 0 ? 2 : xslot - 1);   // (xslot + 2) % 3
+            core.compute(xs + xslot * Core::XB, ys + yslot * Core::YB, lane, wx, wy);
+            if (ks == nk - 1) {
+                const long rbase = tile * 256 + wx * Core::TX + g0 * 4;
+                const bool partial = (tile + 1) * 256 > nrows;
 #pragma unroll
-                for (int x = 0; x < Core::NX; ++x) {
-                    const long r0 = rbase + x * 16;
-                    int4 kv = make_int4(0, 0, 0, 0);
-                    if (gkeys) {
-                        if (r0 + 3 < nrows) kv = *(const int4*)(gkeys + r0);
-                        else {
-                            kv.x = r0 < nrows ? gkeys[r0] : -1;
-                            kv.y = r0 + 1 < nrows ? gkeys[r0 + 1] : -1;
-                            kv.z = r0 + 2 < nrows ? gkeys[r0 + 2] : -1;
-                            kv.w = -1;
+                for (int y = 0; y < NY; ++y) {
+                    float v[NX][4];
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) {
+                        const long r0 = rbase + x * 16;
+                        int kk[4] = {0, 0, 0, 0};
+                        if (USE_KEYS) {
+                            const int4 kv = *(const int4*)(gkeys + r0);   // padded allocation: in bounds
+                            kk[0] = kv.x; kk[1] = kv.y; kk[2] = kv.z; kk[3] = kv.w;
                         }
-                    }
-                    const int kk[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const bool ok = (r0 + j < nrows) &&
-                                            (mykey[y] == -2 ? kk[j] >= 0 : kk[j] == mykey[y]);
-                            const float v = ok ? core.acc[y][x][j] : -INFINITY;
-                            if (v > top[y].s[K - 1]) top[y].template push<false>(v, (int)(r0 + j));
+                            bool ok = true;
+                            if (USE_KEYS) ok = (mykey[y] == -2) ? kk[j] >= 0 : kk[j] == mykey[y];
+                            if (partial) ok = ok && (r0 + j < nrows);
+                            v[x][j] = ok ? core.acc[y][x][j] : -INFINITY;
                         }
+                    }
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) m = fmaxf(fmaxf(m, fmaxf(v[x][0], v[x][1])), fmaxf(v[x][2], v[x][3]));
+                    if (m > top[y].s[K - 1]) {
+#pragma unroll
+                        for (int x = 0; x < NX; ++x)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (v[x][j] > top[y].s[K - 1])
+                                    top[y].template push<false>(v[x][j], (int)(rbase + x * 16 + j));
                     }
                 }
                 core.zero();
+                ks = 0; tile += nb;
+            } else {
+                ++ks;
             }
-            if (!more) break;
-            __syncthreads();
-            cur ^= 1;
-            if (last_k) { ks = 0; tile = ntile; } else { ++ks; }
+            if (s + 2 < S) Core::wait_keep_newest(); else Core::wait_all();
+            __builtin_amdgcn_s_barrier();
+            xslot = xslot == 2 ? 0 : xslot + 1;
+            yslot ^= 1;
         }
     }
 
-    // merge the 8 lists of each query (2 wave rows x 4 lane groups) through LDS
+    // merge the WX*4 lists of each query through LDS, one thread per query
+    constexpr int NL = WX * 4;
     __syncthreads();
-    float* ls = (float*)smem;                  // [64 queries][8 lists][K]
-    int* lr = (int*)(smem + 64 * 8 * K * 4);
+    float* ls = (float*)smem;                       // [RY][NL][K]
+    int* lr = (int*)(smem + RY * NL * K * 4);
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        const int ql = wy * 32 + y * 16 + l15, slot = wx * 4 + g0;
+    for (int y = 0; y < NY; ++y) {
+        const int ql = wy * Core::TY + y * 16 + l15, slot = wx * 4 + g0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            ls[(ql * 8 + slot) * K + i] = top[y].s[i];
-            lr[(ql * 8 + slot) * K + i] = top[y].r[i];
+            ls[(ql * NL + slot) * K + i] = top[y].s[i];
+            lr[(ql * NL + slot) * K + i] = top[y].r[i];
         }
     }
     __syncthreads();
-    if (tid < 64 && q0 + tid < Bq) {
+    if (tid < RY && q0 + tid < Bq) {
         TopK<K> m;
         m.init();
-        for (int c = 0; c < 8 * K; ++c) {
-            const float v = ls[tid * 8 * K + c];
-            const int rr = lr[tid * 8 * K + c];
+        for (int c = 0; c < NL * K; ++c) {
+            const float v = ls[tid * NL * K + c];
+            const int rr = lr[tid * NL * K + c];
             if (rr >= 0 && m.beats_tail(v, rr)) m.template push<true>(v, rr);
         }
-        const size_t o = ((size_t)blockIdx.x * Bq + q0 + tid) * K;
+        const size_t o = ((size_t)gb * Bq + q0 + tid) * K;
 #pragma unroll
         for (int i = 0; i < K; ++i) { part_s[o + i] = m.s[i]; part_r[o + i] = m.r[i]; }
     }
@@ -909,39 +992,68 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStr
     return hipSuccess;
 }
 
-using ScanCore = GemmCore<256, 64, 2, 2, true>;
-static constexpr int kScanLds = 2 * ScanCore::SB;  // 80 KiB >= merge area (64*8*16*8 = 64 KiB)
-
-int scan_max_blocks() { return 512; }
+int scan_max_blocks() { return 256; }
 
 static int scan_klist(int k) { return k <= 5 ? 5 : (k <= 10 ? 10 : 16); }
 int scan_list_len(int k) { return scan_klist(k); }
 
-hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
-                            const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r, int* nblk_out,
-                            hipStream_t s) {
-    if (nrows <= 0 || nrows > 0x7fffff00L || D <= 0 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q || !part_s ||
-        !part_r || !nblk_out)
-        return hipErrorInvalidValue;
-    const long ntiles = (nrows + 255) / 256;
-    const int qtiles = (Bq + 63) / 64;
-    long nb = scan_max_blocks() / (qtiles < 8 ? qtiles : 8);
-    if (nb < 64) nb = 64;
-    if (nb > ntiles) nb = ntiles;
-    *nblk_out = (int)nb;
-    dim3 grid((unsigned)nb, qtiles);
-    const int kl = scan_klist(k);
-    if (kl == 5)
-        hipLaunchKernelGGL((scan_topk_kernel<5>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
-                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
-    else if (kl == 10)
-        hipLaunchKernelGGL((scan_topk_kernel<10>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
-                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
-    else
-        hipLaunchKernelGGL((scan_topk_kernel<16>), grid, dim3(256), kScanLds, s, (const half_t*)g, gk, (long)nrows, D,
-                           (const half_t*)q, qkeys, Bq, part_s, (long long*)part_r);
+static int scan_query_tile(int Bq, int kl) {
+    const int cap = kl == 5 ? 256 : (kl == 10 ? 128 : 64);
+    const int want = Bq <= 64 ? 64 : (Bq <= 128 ? 128 : 256);
+    return want < cap ? want : cap;
+}
+
+template <int K, int RY, int WX, int WY, bool USE_KEYS>
+static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
+                            int Bq, int nb, float* part_s, int64_t* part_r, hipStream_t s, bool attr_only) {
+    using Core = GemmCore8<256, RY, WX, WY, true>;
+    constexpr int merge = RY * WX * 4 * K * 8;
+    constexpr int lds = Core::LDS > merge ? Core::LDS : merge;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = scan_topk8_kernel<K, RY, WX, WY, USE_KEYS>;
+    if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int qtiles = (Bq + RY - 1) / RY;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,
+                       (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r);
     FR_CHECK_LAUNCH();
     return hipSuccess;
+}
+
+static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const int32_t* gk, long nrows, int D,
+                                const void* q, const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr,
+                                hipStream_t s, bool attr) {
+#define FR_SCAN(K, RY, WX, WY)                                                                              \
+    if (kl == K && ry == RY)                                                                                  \
+        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, s, attr)      \
+                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, s, attr);
+    FR_SCAN(5, 64, 4, 2)
+    FR_SCAN(5, 128, 4, 2)
+    FR_SCAN(5, 256, 2, 4)
+    FR_SCAN(10, 64, 4, 2)
+    FR_SCAN(10, 128, 4, 2)
+    FR_SCAN(16, 64, 4, 2)
+#undef FR_SCAN
+    return hipErrorInvalidValue;
+}
+
+// `use_keys`: apply the per-row key test (needed when query keys are given or the gallery
+// may hold dead rows).  The gallery buffers must be padded to a multiple of 256 rows.
+hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
+                            const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
+                            int* nblk_out, hipStream_t s) {
+    if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q ||
+        !part_s || !part_r || !nblk_out || (use_keys && !gk))
+        return hipErrorInvalidValue;
+    const int kl = scan_klist(k);
+    const int ry = scan_query_tile(Bq, kl);
+    const int qtiles = (Bq + ry - 1) / ry;
+    const long ntiles = (nrows + 255) / 256;
+    int nb = (scan_max_blocks() / qtiles) & ~7;
+    if (nb < 8) nb = 8;
+    const long nt8 = (ntiles + 7) & ~7L;
+    if (nb > nt8) nb = (int)nt8;
+    *nblk_out = nb;
+    return scan_dispatch(kl, ry, use_keys != 0, g, gk, (long)nrows, D, q, qkeys, Bq, nb, part_s, part_r, s, false);
 }
 
 hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
@@ -975,12 +1087,14 @@ hipError_t kernels_init() {
     hipError_t e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)scan_topk_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)scan_topk_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)scan_topk_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
-    return e;
+    static const int combos[][2] = {{5, 64}, {5, 128}, {5, 256}, {10, 64}, {10, 128}, {16, 64}};
+    for (const auto& c : combos)
+        for (int keys = 0; keys < 2; ++keys) {
+            e = scan_dispatch(c[0], c[1], keys != 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                              nullptr, true);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
 }
 
 }  // namespace frhot
