@@ -112,105 +112,6 @@ struct GemmCore {
     }
 };
 
-// ------------------------------------------------------ 3x3 conv (igemm) ---
-// Output pixels are enumerated window-major: m = ((b*H/2 + wy)*W/2 + wx)*4 + dy*2 + dx,
-// so four consecutive m are one 2x2 pooling window and, with pixels on the MFMA
-// lanes, a window is one lane quad.
-template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RX, int RY, int WX, int WY>
-__global__ __launch_bounds__(256) void conv3x3_igemm_kernel(const half_t* __restrict__ x,
-                                                            const half_t* __restrict__ w,
-                                                            const float* __restrict__ bias,
-                                                            half_t* __restrict__ y, int batch) {
-    using Core = GemmCore<RX, RY, WX, WY, false>;
-    constexpr int H = HW, W = HW, PW = W + 2, HALF = W / 2;
-    constexpr int K = 9 * CIN, CPK = CIN / 64, NK = 9 * CPK;
-    constexpr int NT = COUT / RY;
-    static_assert(CIN % 64 == 0 && COUT % RY == 0, "channel tiling");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wx = wave / WY, wy = wave % WY;
-    const long M = (long)batch * H * W;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const long m0 = (long)(bid / NT) * RX;
-    const int n0 = (bid % NT) * RY;
-
-    const char* xp[Core::NPX];
-    const char* yp[Core::NPY];
-    const int cb = Core::stage_chunk_bytes(lane);
-#pragma unroll
-    for (int i = 0; i < Core::NPX; ++i) {
-        long m = m0 + Core::stage_row(wave, lane, i);
-        m = m < M ? m : M - 1;
-        const int b = (int)(m / (H * W));
-        const int rem = (int)(m % (H * W));
-        const int win = rem >> 2, d = rem & 3;
-        const int py = 2 * (win / HALF) + (d >> 1), px = 2 * (win % HALF) + (d & 1);
-        xp[i] = (const char*)x + ((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb;
-    }
-#pragma unroll
-    for (int i = 0; i < Core::NPY; ++i)
-        yp[i] = (const char*)w + ((long)(n0 + Core::stage_row(wave, lane, i)) * K) * 2 + cb;
-
-    Core core;
-    core.zero();
-
-    int r = 0, s = 0, cc = 0;  // tap row, tap column, 64-channel chunk of the NEXT step to stage
-    auto next_xoff = [&]() -> size_t {
-        size_t off = ((size_t)(r * PW + s) * CIN + cc * 64) * 2;
-        if (++cc == CPK) { cc = 0; if (++s == 3) { s = 0; ++r; } }
-        return off;
-    };
-
-    Core::issue(smem, wave, xp, next_xoff(), yp, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = 0; ks < NK - 1; ++ks) {
-        Core::issue(smem + (cur ^ 1) * Core::SB, wave, xp, next_xoff(), yp, (size_t)(ks + 1) * 128);
-        core.compute(smem + cur * Core::SB, lane, wx, wy);
-        __syncthreads();
-        cur ^= 1;
-    }
-    core.compute(smem + cur * Core::SB, lane, wx, wy);
-
-    // Epilogue: lane = pixel (lane & 15), registers = 4 consecutive channels.
-    constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
-    constexpr int OW = WO + 2 * OPAD, OH = HO + 2 * OPAD;
-    const int l15 = lane & 15, g0 = lane >> 4;
-#pragma unroll
-    for (int px = 0; px < Core::NX; ++px) {
-        const long m = m0 + wx * Core::TX + px * 16 + l15;
-        const bool live = m < M;
-        const long mm = live ? m : M - 1;
-        const int b = (int)(mm / (H * W));
-        const int rem = (int)(mm % (H * W));
-        const int win = rem >> 2, d = rem & 3;
-        int oy, ox;
-        if (POOL) { oy = win / HALF; ox = win % HALF; }
-        else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
-        half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
-#pragma unroll
-        for (int cy = 0; cy < Core::NY; ++cy) {
-            const int c = n0 + wy * Core::TY + cy * 16 + g0 * 4;
-            const float4v bv = *(const float4v*)(bias + c);
-            float4v v = core.acc[cy][px];
-            if (POOL) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = v[j];
-                    t = fmaxf(t, __shfl_xor(t, 1));
-                    t = fmaxf(t, __shfl_xor(t, 2));
-                    v[j] = t;
-                }
-            }
-            half4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(v[j] + bv[j], 0.f);
-            if (live && (!POOL || (lane & 3) == 0)) *(half4*)(orow + c) = o;
-        }
-    }
-}
-
 // ------------------------------------------------------------ conv1_1 ------
 // 3 -> 64 channels.  Input fp16 [B,226,226,4] (4th channel zero), weights
 // fp16 [64][64] with k = tap*4 + c for k < 36 and zeros after.  K is covered by two
@@ -639,6 +540,157 @@ struct GemmCore8 {
     }
 };
 
+// 3x3 convolution as a persistent implicit GEMM on the 8-wave ring core.  Block w walks
+// output tiles w, w+G, ... (tile = 256 window-major pixels x RY channels, channel tile
+// fastest); the (tile, k-step) sequence is one pipeline, so the next tile's operands are
+// in flight while this tile's epilogue stores.  Every wave issues the same number of
+// vector-memory instructions per step (dead pixels store to `dump`), which lets the end
+// of a tile's last step leave its stores in flight behind a counted wait.
+template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RY, int WX, int WY>
+__global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restrict__ x,
+                                                           const half_t* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           half_t* __restrict__ y, half_t* __restrict__ dump,
+                                                           int batch) {
+    using Core = GemmCore8<256, RY, WX, WY, false>;
+    constexpr int H = HW, W = HW, PW = W + 2, HALF = W / 2;
+    constexpr int K = 9 * CIN, CPK = CIN / 64, NK = 9 * CPK;
+    constexpr int NT = COUT / RY;
+    constexpr int NX = Core::NX, NY = Core::NY, NST = NX * NY;
+    static_assert(CIN % 64 == 0 && COUT % RY == 0, "channel tiling");
+    static_assert(4 + NST <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs = smem;
+    char* const ys = smem + Core::XS * Core::XB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = wave / WY, wy = wave % WY;
+    const int l15 = lane & 15, g0 = lane >> 4;
+    const long M = (long)batch * H * W;
+    const long ntiles = ((M + 255) / 256) * NT;
+    const int G = gridDim.x;
+    const int wk = xcd_remap(blockIdx.x, G);
+    const long my_tiles = wk < ntiles ? (ntiles - wk + G - 1) / G : 0;
+    const long S = my_tiles * NK;
+    if (S == 0) return;
+    const int cb = Core::stage_chunk_bytes(lane);
+    const int n0 = (wk % NT) * RY;     // G is a multiple of NT: the channel tile never changes
+
+    const char* xp[Core::NPX];
+    const char* yp[Core::NPY];
+    auto set_pixels = [&](long tile) {
+        const long m0 = (tile / NT) * 256;
+#pragma unroll
+        for (int i = 0; i < Core::NPX; ++i) {
+            long m = m0 + Core::stage_row(wave, lane, i);
+            m = m < M ? m : M - 1;
+            const int b = (int)(m / (H * W));
+            const int rem = (int)(m % (H * W));
+            const int win = rem >> 2, d = rem & 3;
+            const int py = 2 * (win / HALF) + (d >> 1), px = 2 * (win % HALF) + (d & 1);
+            xp[i] = (const char*)x + ((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < Core::NPY; ++i)
+        yp[i] = (const char*)w + ((long)(n0 + Core::stage_row(wave, lane, i)) * K) * 2 + cb;
+
+    // Bias of this wave's channels, fetched and waited for before the pipeline starts: an
+    // ordinary load inside the loop would make the compiler drain the LDS-DMA queue.
+    float4v bv[NY];
+#pragma unroll
+    for (int cy = 0; cy < NY; ++cy) {
+        bv[cy] = *(const float4v*)(bias + n0 + wy * Core::TY + cy * 16 + g0 * 4);
+        asm volatile("" ::"v"(bv[cy][0]), "v"(bv[cy][1]), "v"(bv[cy][2]), "v"(bv[cy][3]));
+    }
+
+    long itile = wk;                 // issue side: tile and tap position of the next streamed step
+    int ir = 0, is = 0, icc = 0, yks = 0;
+    set_pixels(itile);
+    auto next_x = [&](int slot) {
+        const size_t off = ((size_t)(ir * PW + is) * CIN + icc * 64) * 2;
+        Core::issue_x(xs + slot * Core::XB, wave, xp, off);
+        if (++icc == CPK) {
+            icc = 0;
+            if (++is == 3) {
+                is = 0;
+                if (++ir == 3) { ir = 0; itile += G; set_pixels(itile < ntiles ? itile : ntiles - 1); }
+            }
+        }
+    };
+    auto next_y = [&](int slot) {
+        Core::issue_y(ys + slot * Core::YB, wave, yp, (size_t)yks * 128);
+        if (++yks == NK) yks = 0;
+    };
+
+    Core core;
+    core.zero();
+    next_y(0);
+    next_x(0);
+    if (S > 1) { next_x(1); Core::wait_keep_newest(); } else { Core::wait_all(); }
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int HO = POOL ? H / 2 : H, WO = POOL ? W / 2 : W;
+    constexpr int OW = WO + 2 * OPAD, OH = HO + 2 * OPAD;
+    int xslot = 0, yslot = 0, ks = 0;
+    long tile = wk;
+    for (long s = 0; s < S; ++s) {
+        if (s + 1 < S) next_y(yslot ^ 1);
+        if (s + 2 < S) next_x(xslot == 0 ? 2 : xslot - 1);
+        core.compute(xs + xslot * Core::XB, ys + yslot * Core::YB, lane, wx, wy);
+        const bool tile_end = (ks == NK - 1);
+        if (tile_end) {
+            const long m0 = (tile / NT) * 256;
+#pragma unroll
+            for (int px = 0; px < NX; ++px) {
+                const long m = m0 + wx * Core::TX + px * 16 + l15;
+                const bool live = m < M;
+                const long mm = live ? m : M - 1;
+                const int b = (int)(mm / (H * W));
+                const int rem = (int)(mm % (H * W));
+                const int win = rem >> 2, d = rem & 3;
+                int oy, ox;
+                if (POOL) { oy = win / HALF; ox = win % HALF; }
+                else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
+                half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
+#pragma unroll
+                for (int cy = 0; cy < NY; ++cy) {
+                    const int c = n0 + wy * Core::TY + cy * 16 + g0 * 4;
+                    float4v v = core.acc[cy][px];
+                    if (POOL) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float t = v[j];
+                            t = fmaxf(t, __shfl_xor(t, 1));
+                            t = fmaxf(t, __shfl_xor(t, 2));
+                            v[j] = t;
+                        }
+                    }
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(v[j] + bv[cy][j], 0.f);
+                    half_t* dst = live ? orow + c : dump + lane * 4;   // unconditional: fixed op count
+                    *(half4*)dst = o;
+                }
+            }
+            core.zero();
+            ks = 0; tile += G;
+        } else {
+            ++ks;
+        }
+        if (s + 2 < S) {
+            if (tile_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
+            else Core::wait_keep_newest();
+        } else {
+            Core::wait_all();
+        }
+        __builtin_amdgcn_s_barrier();
+        xslot = xslot == 2 ? 0 : xslot + 1;
+        yslot ^= 1;
+    }
+}
+
 // Gallery scan, 8 waves: gallery tile 256 rows (MFMA A operand), query tile RY in
 // {64,128,256} (B operand, one query per lane & 15).  The 1-D grid holds nb gallery
 // walkers per query tile; walker gb visits gallery tiles gb, gb+nb, ...  Blocks that
@@ -844,48 +896,49 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
 // ---------------------------------------------------------------- launch ---
 #define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RX, int RY, int WX, int WY>
-static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, int B, hipStream_t s,
-                                   bool set_attr_only) {
-    using Core = GemmCore<RX, RY, WX, WY, false>;
-    auto kern = conv3x3_igemm_kernel<HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY>;
-    constexpr int lds = 2 * Core::SB;
+template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RY, int WX, int WY>
+static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
+                                   hipStream_t s, bool set_attr_only) {
+    using Core = GemmCore8<256, RY, WX, WY, false>;
+    auto kern = conv3x3_ring_kernel<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>;
+    constexpr int lds = Core::LDS;
     if (set_attr_only)
         return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long M = (long)B * HW * HW;
-    const long mt = (M + RX - 1) / RX;
-    const long nblk = mt * (COUT / RY);
-    if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, (const half_t*)x, (const half_t*)w, bias,
-                       (half_t*)y, B);
+    const long ntiles = ((M + 255) / 256) * (COUT / RY);
+    long grid = 256;                       // one walker per CU; a multiple of COUT / RY
+    if (grid > ntiles) grid = (ntiles + 1) & ~1L;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
+                       (half_t*)y, (half_t*)dump, B);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
 
 static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y,
-                                int B, hipStream_t s, bool attr) {
-#define FR_CONV(HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY)                                                  \
+                                void* dump, int B, hipStream_t s, bool attr) {
+#define FR_CONV(HW, CIN, COUT, POOL, OPAD, RY, WX, WY)                                                       \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD)           \
-        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RX, RY, WX, WY>(x, w, bias, y, B, s, attr);
-    FR_CONV(224, 64, 64, true, 1, 256, 64, 4, 1)
-    FR_CONV(112, 64, 128, false, 1, 256, 128, 2, 2)
-    FR_CONV(112, 128, 128, true, 1, 256, 128, 2, 2)
-    FR_CONV(56, 128, 256, false, 1, 256, 128, 2, 2)
-    FR_CONV(56, 256, 256, false, 1, 256, 128, 2, 2)
-    FR_CONV(56, 256, 256, true, 1, 256, 128, 2, 2)
-    FR_CONV(28, 256, 512, false, 1, 256, 128, 2, 2)
-    FR_CONV(28, 512, 512, false, 1, 256, 128, 2, 2)
-    FR_CONV(28, 512, 512, true, 1, 256, 128, 2, 2)
-    FR_CONV(14, 512, 512, false, 1, 256, 128, 2, 2)
-    FR_CONV(14, 512, 512, true, 0, 256, 128, 2, 2)
+        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>(x, w, bias, y, dump, B, s, attr);
+    FR_CONV(224, 64, 64, true, 1, 64, 4, 2)
+    FR_CONV(112, 64, 128, false, 1, 128, 4, 2)
+    FR_CONV(112, 128, 128, true, 1, 128, 4, 2)
+    FR_CONV(56, 128, 256, false, 1, 256, 2, 4)
+    FR_CONV(56, 256, 256, false, 1, 256, 2, 4)
+    FR_CONV(56, 256, 256, true, 1, 256, 2, 4)
+    FR_CONV(28, 256, 512, false, 1, 256, 2, 4)
+    FR_CONV(28, 512, 512, false, 1, 256, 2, 4)
+    FR_CONV(28, 512, 512, true, 1, 256, 2, 4)
+    FR_CONV(14, 512, 512, false, 1, 256, 2, 4)
+    FR_CONV(14, 512, 512, true, 0, 256, 2, 4)
 #undef FR_CONV
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y, int B,
-                          hipStream_t s) {
-    if (B <= 0 || !x || !w || !bias || !y) return hipErrorInvalidValue;
-    return conv_dispatch(d, x, w, bias, y, B, s, false);
+// `dump` is >= 512 bytes of scratch that dead lanes of a partial tile store to.
+hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y,
+                          void* dump, int B, hipStream_t s) {
+    if (B <= 0 || !x || !w || !bias || !y || !dump) return hipErrorInvalidValue;
+    return conv_dispatch(d, x, w, bias, y, dump, B, s, false);
 }
 
 hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y, int B, hipStream_t s) {
@@ -1081,7 +1134,7 @@ hipError_t kernels_init() {
         {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
     };
     for (const auto& d : layers) {
-        hipError_t e = conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
+        hipError_t e = conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
         if (e != hipSuccess) return e;
     }
     hipError_t e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
