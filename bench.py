@@ -71,7 +71,7 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     g32 = g16.astype(np.float32)
     qd = ref[:, :args.dim]
     t0 = time.perf_counter()
-    s_ref, r_ref = osr.cosine_topk(qd, g32, args.k)
+    s_ref, r_ref = osr.cosine_topk_fast(qd, g32, args.k)
     t_scan = (time.perf_counter() - t0) / nf * (args.gallery_rows / ns)
     # gate: over the full shard the GPU must return, for every sampled query, scores that are
     # the true dot products of the rows it names and no sampled row may beat its k-th score
@@ -108,12 +108,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from frhot import synth
+    from frhot.dist import ShardedSearch, shard_rows
     from frhot.engine import Context, Gallery
     from frhot.weights import pack_blob, synthetic_weights
 
     P, B, D, K = world, args.batch, args.dim, args.k
-    rows_local = (args.gallery_rows + P - 1) // P
-    row_base = rank * rows_local
+    row_base, rows_local = shard_rows(args.gallery_rows, P, rank)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = Context(device=local_rank, max_batch=B, stream=stream.cuda_stream)
@@ -125,25 +125,20 @@ def main():
         gal.fill_synthetic(seed=args.seed + 1000 * (rank + 1), row0=0, n=rows_local, nkeys=0, dup_every=100)
 
         q_local = torch.empty((B, D), dtype=torch.float16, device=dev)
-        q_all = torch.empty((P * B, D), dtype=torch.float16, device=dev) if P > 1 else q_local
-        s_local = torch.empty((P * B, K), dtype=torch.float32, device=dev)
-        r_local = torch.empty((P * B, K), dtype=torch.int64, device=dev)
-        if P > 1:
-            s_all = torch.empty((P, P * B, K), dtype=torch.float32, device=dev)
-            r_all = torch.empty((P, P * B, K), dtype=torch.int64, device=dev)
-            out_s = torch.empty((P * B, K), dtype=torch.float32, device=dev)
-            out_r = torch.empty((P * B, K), dtype=torch.int64, device=dev)
         flags = Context.flags(gamma=True, flip=True)
+
+        def search_local(q_all, s_out, r_out):
+            gal.search_dev(q_all.data_ptr(), None, q_all.shape[0], K, s_out.data_ptr(), r_out.data_ptr(), row_base)
+
+        def merge(s_all, r_all, out_s, out_r):
+            ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, P * B, K, out_s.data_ptr(), out_r.data_ptr())
+
+        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge)
+        last = {}
 
         def step():
             ctx.embed_dev(crops_dev.data_ptr(), offsets, hw, strides, flags, None, q_local.data_ptr(), D)
-            if P > 1:
-                dist.all_gather_into_tensor(q_all, q_local)
-            gal.search_dev(q_all.data_ptr(), None, P * B, K, s_local.data_ptr(), r_local.data_ptr(), row_base)
-            if P > 1:
-                dist.all_gather_into_tensor(s_all, s_local)
-                dist.all_gather_into_tensor(r_all, r_local)
-                ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, P * B, K, out_s.data_ptr(), out_r.data_ptr())
+            last["s"], last["r"] = sharded(q_local)
 
         for _ in range(args.warmup):
             step()
@@ -166,8 +161,8 @@ def main():
             elapsed = float(t.item())
 
         # sanity on the last step's answer: every query found k rows, scores descending
-        res_s = (out_s if P > 1 else s_local).cpu().numpy()
-        res_r = (out_r if P > 1 else r_local).cpu().numpy()
+        res_s = last["s"].cpu().numpy()
+        res_r = last["r"].cpu().numpy()
         sane = bool((res_r >= 0).all() and (np.diff(res_s, axis=1) <= 0).all() and np.isfinite(res_s).all())
 
         line = None

@@ -31,7 +31,7 @@ hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float sc
                                  void* x0_f16, int B, hipStream_t s);
 hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y,
                           int B, hipStream_t s);
-// `dump`: >= 512 bytes of device scratch (dead lanes of a partial tile store there).
+// `dump`: >= 1 KiB of device scratch (dead lanes of a partial tile store there).
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias,
                           void* y, void* dump, int B, hipStream_t s);
 // Split-K GEMM partial[z][m][n] = sum_{k in slice z} x[m][k] * w[n][k]; M rows of x,

@@ -116,12 +116,17 @@ struct GemmCore {
 // 3 -> 64 channels.  Input fp16 [B,226,226,4] (4th channel zero), weights
 // fp16 [64][64] with k = tap*4 + c for k < 36 and zeros after.  K is covered by two
 // 16x16x32 MFMAs (taps 0..7, then tap 8 + zero padding).
-// Each wave turns 16 consecutive pixels of a row into 16 x 64 outputs per step.
+// Each wave turns 16 consecutive pixels of a row into 16 x 64 outputs per step and
+// stores them as two fully coalesced 1-KiB rows-of-pixels through a wave-private LDS
+// transpose (the accumulator holds 4 channels x 1 pixel per lane; a store wants 8 lanes
+// x 16 B per pixel).
 __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__ x0,
                                                       const half_t* __restrict__ w64,
                                                       const float* __restrict__ bias,
                                                       half_t* __restrict__ y, int ntiles) {
     constexpr int P = 226, T = 14;  // padded width, 16-pixel tiles per row
+    constexpr int PITCH = 144;      // bytes per pixel row in LDS: 128 + 16 keeps ds_read_b128 aligned
+    __shared__ __attribute__((aligned(16))) char tr[4][16 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     half8 a0[4], a1[4];
@@ -136,18 +141,20 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__
     const int t0 = 2 * g, t1 = 2 * g + 1;
     const int off0 = ((t0 / 3) * P + (t0 % 3)) * 4, off1 = ((t1 / 3) * P + (t1 % 3)) * 4;
     const int off8 = (2 * P + 2) * 4;
+    char* const my = tr[wave];
+    char* const wr_at = my + l15 * PITCH + g * 8;               // + ct*32
+    const char* const rd_at = my + (lane >> 3) * PITCH + (lane & 7) * 16;   // pixel lane>>3 (+8), chunk lane&7
     const int nw = gridDim.x * 4;
     for (int t = blockIdx.x * 4 + wave; t < ntiles; t += nw) {
         const int b = t / (224 * T), rem = t % (224 * T);
-        const int py = rem / T, px = (rem % T) * 16 + l15;
-        const half_t* src = x0 + (((long)b * P + py) * P + px) * 4;
+        const int py = rem / T, px0 = (rem % T) * 16;
+        const half_t* src = x0 + (((long)b * P + py) * P + px0 + l15) * 4;
         const half4 v0 = *(const half4*)(src + off0);
         const half4 v1 = *(const half4*)(src + off1);
         const half4 v8 = *(const half4*)(src + off8);
         const half_t z = (half_t)0.f;
         const half8 bf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const half8 bf1 = {v8[0], v8[1], v8[2], v8[3], z, z, z, z};   // weights are zero beyond k = 35
-        half_t* dst = y + (((long)b * P + py + 1) * P + px + 1) * 64 + g * 4;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             float4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -156,8 +163,16 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__
             half4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(acc[j] + bv[ct][j], 0.f);
-            *(half4*)(dst + ct * 16) = o;
+            *(half4*)(wr_at + ct * 32) = o;
         }
+        __builtin_amdgcn_wave_barrier();
+        const half8 r0 = *(const half8*)rd_at;
+        const half8 r1 = *(const half8*)(rd_at + 8 * PITCH);
+        __builtin_amdgcn_wave_barrier();
+        // 16 output pixels are 2 KiB contiguous in the NHWC row: lane -> 16 B at lane*16 (+1 KiB)
+        char* dst = (char*)(y + (((long)b * P + py + 1) * P + px0 + 1) * 64) + lane * 16;
+        *(half8*)dst = r0;
+        *(half8*)(dst + 1024) = r1;
     }
 }
 
@@ -285,58 +300,72 @@ __global__ __launch_bounds__(256) void fc_reduce_relu_l2_kernel(const float* __r
 // maximum byte (DeepFace divides by 255 only when it exceeds 1).
 __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ crops,
                                                         const CropMeta* __restrict__ meta,
-                                                        const uint8_t* __restrict__ lut, int flip,
+                                                        const uint8_t* __restrict__ lut_g, int flip,
                                                         uint8_t* __restrict__ out, int* __restrict__ out_max) {
+    __shared__ uint8_t lut[256];
+    __shared__ int red[4];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;  // pixel inside 224x224
-    const CropMeta mt = meta[b];
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    // blockIdx.y is uniform, so these become scalar loads
+    const long offset = meta[b].offset;
+    const int sh = meta[b].h, sw = meta[b].w, stride = meta[b].stride;
+    const int dw = meta[b].dw, dh = meta[b].dh, padx = meta[b].padx, pady = meta[b].pady;
+    const int area2x = meta[b].area2x;
+    const double scale_x = meta[b].scale_x, scale_y = meta[b].scale_y;
+    __syncthreads();
+    const uint8_t* src = crops + offset;
+    const int c0 = flip ? 2 : 0, c2 = flip ? 0 : 2;
     int vmax = 0;
-    if (p < 224 * 224) {
-        const int oy = p / 224, ox = p % 224;
-        const int dy = oy - mt.pady, dx = ox - mt.padx;
-        uint8_t res[3] = {0, 0, 0};
-        if (dy >= 0 && dy < mt.dh && dx >= 0 && dx < mt.dw) {
-            const uint8_t* src = crops + mt.offset;
-            if (mt.area2x) {
-                const uint8_t* r0 = src + (size_t)(2 * dy) * mt.stride + 6 * dx;
-                const uint8_t* r1 = r0 + mt.stride;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int sc = flip ? 2 - c : c;
-                    const int sum = lut[r0[sc]] + lut[r0[3 + sc]] + lut[r1[sc]] + lut[r1[3 + sc]];
-                    res[c] = (uint8_t)((sum + 2) >> 2);
-                }
+    // 8 output rows per block, 7 pixels per thread
+    for (int it = 0; it < 7; ++it) {
+        const int p = blockIdx.x * 1792 + it * 256 + threadIdx.x;
+        const int oy = p / 224, ox = p - oy * 224;
+        const int dy = oy - pady, dx = ox - padx;
+        int r0v = 0, r1v = 0, r2v = 0;
+        if (dy >= 0 && dy < dh && dx >= 0 && dx < dw) {
+            if (area2x) {
+                const uint8_t* q0 = src + (size_t)(2 * dy) * stride + 6 * dx;
+                const uint8_t* q1 = q0 + stride;
+                r0v = (lut[q0[c0]] + lut[q0[3 + c0]] + lut[q1[c0]] + lut[q1[3 + c0]] + 2) >> 2;
+                r1v = (lut[q0[1]] + lut[q0[4]] + lut[q1[1]] + lut[q1[4]] + 2) >> 2;
+                r2v = (lut[q0[c2]] + lut[q0[3 + c2]] + lut[q1[c2]] + lut[q1[3 + c2]] + 2) >> 2;
             } else {
-                float fx = (float)(((double)dx + 0.5) * mt.scale_x - 0.5);
+                float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
                 int sx = (int)floorf(fx);
                 fx -= (float)sx;
                 if (sx < 0) { fx = 0.f; sx = 0; }
-                if (sx >= mt.w - 1) { fx = 0.f; sx = mt.w - 1; }
+                if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
                 const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
-                const int sx1 = min(sx + 1, mt.w - 1);
-                float fy = (float)(((double)dy + 0.5) * mt.scale_y - 0.5);
+                const int sx1 = min(sx + 1, sw - 1);
+                float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
                 int sy = (int)floorf(fy);
                 fy -= (float)sy;
                 const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
-                const int sy0 = min(max(sy, 0), mt.h - 1), sy1 = min(max(sy + 1, 0), mt.h - 1);
-                const uint8_t* r0 = src + (size_t)sy0 * mt.stride;
-                const uint8_t* r1 = src + (size_t)sy1 * mt.stride;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int sc = flip ? 2 - c : c;
-                    const int s0 = lut[r0[3 * sx + sc]] * a0 + lut[r0[3 * sx1 + sc]] * a1;
-                    const int s1 = lut[r1[3 * sx + sc]] * a0 + lut[r1[3 * sx1 + sc]] * a1;
-                    res[c] = (uint8_t)((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2);
-                }
+                const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+                const uint8_t* q0 = src + (size_t)sy0 * stride;
+                const uint8_t* q1 = src + (size_t)sy1 * stride;
+                const uint8_t* p00 = q0 + 3 * sx; const uint8_t* p01 = q0 + 3 * sx1;
+                const uint8_t* p10 = q1 + 3 * sx; const uint8_t* p11 = q1 + 3 * sx1;
+                auto mix = [&](int c) {
+                    const int s0 = lut[p00[c]] * a0 + lut[p01[c]] * a1;
+                    const int s1 = lut[p10[c]] * a0 + lut[p11[c]] * a1;
+                    return (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                };
+                r0v = mix(c0); r1v = mix(1); r2v = mix(c2);
             }
         }
         uint8_t* o = out + ((size_t)b * 224 * 224 + p) * 3;
-        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
-        vmax = max(max((int)res[0], (int)res[1]), (int)res[2]);
+        o[0] = (uint8_t)r0v; o[1] = (uint8_t)r1v; o[2] = (uint8_t)r2v;
+        vmax = max(vmax, max(r0v, max(r1v, r2v)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o));
-    if ((threadIdx.x & 63) == 0 && vmax > 0) atomicMax(out_max + b, vmax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m > 0) atomicMax(out_max + b, m);
+    }
 }
 
 // Stage 2: float conversion (x/255 when the image maximum exceeds 1, *255, minus the
@@ -556,8 +585,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     constexpr int H = HW, W = HW, PW = W + 2, HALF = W / 2;
     constexpr int K = 9 * CIN, CPK = CIN / 64, NK = 9 * CPK;
     constexpr int NT = COUT / RY;
-    constexpr int NX = Core::NX, NY = Core::NY, NST = NX * NY;
-    static_assert(CIN % 64 == 0 && COUT % RY == 0, "channel tiling");
+    constexpr int NX = Core::NX, NY = Core::NY, NST = NX * NY / 2;
+    static_assert(CIN % 64 == 0 && COUT % RY == 0 && NY % 2 == 0, "channel tiling");
     static_assert(4 + NST <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs = smem;
@@ -592,16 +621,23 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
             xp[i] = (const char*)x + ((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb;
         }
     };
+    // LDS row r of the weight tile holds output channel n0 + chan(r), permuted so that the
+    // accumulators of channel-tile pair (2u, 2u+1) give every lane 8 CONSECUTIVE channels:
+    // row = wy*TY + cy*16 + g*4 + j  ->  channel wy*TY + (cy/2)*32 + g*8 + (cy&1)*4 + j.
 #pragma unroll
-    for (int i = 0; i < Core::NPY; ++i)
-        yp[i] = (const char*)w + ((long)(n0 + Core::stage_row(wave, lane, i)) * K) * 2 + cb;
+    for (int i = 0; i < Core::NPY; ++i) {
+        const int r = Core::stage_row(wave, lane, i);
+        const int in = r % Core::TY, cy = in >> 4, g = (in >> 2) & 3, j = in & 3;
+        const int ch = (r / Core::TY) * Core::TY + (cy >> 1) * 32 + g * 8 + (cy & 1) * 4 + j;
+        yp[i] = (const char*)w + ((long)(n0 + ch) * K) * 2 + cb;
+    }
 
-    // Bias of this wave's channels, fetched and waited for before the pipeline starts: an
+    // Bias of this lane's channels, fetched and waited for before the pipeline starts: an
     // ordinary load inside the loop would make the compiler drain the LDS-DMA queue.
     float4v bv[NY];
 #pragma unroll
     for (int cy = 0; cy < NY; ++cy) {
-        bv[cy] = *(const float4v*)(bias + n0 + wy * Core::TY + cy * 16 + g0 * 4);
+        bv[cy] = *(const float4v*)(bias + n0 + wy * Core::TY + (cy >> 1) * 32 + g0 * 8 + (cy & 1) * 4);
         asm volatile("" ::"v"(bv[cy][0]), "v"(bv[cy][1]), "v"(bv[cy][2]), "v"(bv[cy][3]));
     }
 
@@ -655,23 +691,29 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
                 else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
                 half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
 #pragma unroll
-                for (int cy = 0; cy < NY; ++cy) {
-                    const int c = n0 + wy * Core::TY + cy * 16 + g0 * 4;
-                    float4v v = core.acc[cy][px];
-                    if (POOL) {
+                for (int u = 0; u < NY / 2; ++u) {
+                    const int c = n0 + wy * Core::TY + u * 32 + g0 * 8;
+                    half8 o;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float t = v[j];
-                            t = fmaxf(t, __shfl_xor(t, 1));
-                            t = fmaxf(t, __shfl_xor(t, 2));
-                            v[j] = t;
+                    for (int h = 0; h < 2; ++h) {
+                        float4v v = core.acc[2 * u + h][px];
+                        if (POOL) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float t = v[j];
+                                t = fmaxf(t, __shfl_xor(t, 1));
+                                t = fmaxf(t, __shfl_xor(t, 2));
+                                v[j] = t;
+                            }
                         }
-                    }
-                    half4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(v[j] + bv[cy][j], 0.f);
-                    half_t* dst = live ? orow + c : dump + lane * 4;   // unconditional: fixed op count
-                    *(half4*)dst = o;
+                        for (int j = 0; j < 4; ++j) o[4 * h + j] = (half_t)fmaxf(v[j] + bv[2 * u + h][j], 0.f);
+                    }
+                    // Every wave issues this store (dead pixels go to `dump`): the counted wait
+                    // below relies on a fixed number of vector-memory ops per step.  Pooled
+                    // layers store from the quad leader only; its EXEC is never empty.
+                    half_t* dst = live ? orow + c : dump + lane * 8;
+                    if (!POOL || (lane & 3) == 0) *(half8*)dst = o;
                 }
             }
             core.zero();
@@ -934,7 +976,7 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
     return hipErrorInvalidValue;
 }
 
-// `dump` is >= 512 bytes of scratch that dead lanes of a partial tile store to.
+// `dump` is >= 1 KiB of scratch that dead lanes of a partial tile store to.
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y,
                           void* dump, int B, hipStream_t s) {
     if (B <= 0 || !x || !w || !bias || !y || !dump) return hipErrorInvalidValue;
@@ -990,7 +1032,7 @@ hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const ui
     if (B <= 0 || !crops || !meta || !lut || !out || !out_max) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(out_max, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(resize_u8_kernel, dim3(196, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(28, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

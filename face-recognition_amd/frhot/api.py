@@ -1,0 +1,90 @@
+"""FastAPI surface of the recognition path: the two handlers of the reference's
+face router (app/src/api/routers/face.py:57-72,90-110) behind its X-API-Key check
+(app/src/api/routes.py:17-28), wired to the GPU engine.
+
+`create_app(ctx)` builds everything in one process: context -> micro-batcher ->
+GalleryService -> DatabaseClient -> FaceService.  The request models repeat the
+reference's field set (app/src/core/models.py:11-28,43-54).
+"""
+from __future__ import annotations
+
+import logging
+
+from fastapi import APIRouter, Depends, FastAPI, HTTPException, Security, status
+from fastapi.responses import JSONResponse
+from fastapi.security import APIKeyHeader
+from pydantic import BaseModel
+
+logger = logging.getLogger(__name__)
+DEFAULT_API_KEY = "mac_dinh"   # app/config/settings.py:58
+
+
+class CreateFace(BaseModel):
+    img_base64: str = None
+    id: str = None
+    name: str = None
+    role: str = None
+    store_id: str = None
+    is_update: bool = False
+
+
+class FaceRecog(BaseModel):
+    img_base64: str = None
+    role: str = None
+    store_id: str = None
+
+
+def build_router(face_service, api_key: str = DEFAULT_API_KEY) -> APIRouter:
+    api_key_header = APIKeyHeader(name="X-API-Key", auto_error=False)
+
+    async def verify_api_key(key: str = Security(api_key_header)):
+        if key == api_key:
+            return key
+        raise HTTPException(status_code=status.HTTP_403_FORBIDDEN,
+                            detail="Could not validate credentials - Access Denied")
+
+    router = APIRouter(tags=["Face"], dependencies=[Depends(verify_api_key)])
+
+    @router.post("/face_recog_img_base64")
+    async def face_recog_img_base64(data: FaceRecog):
+        try:
+            return await face_service.recognize_face(data)
+        except Exception as e:
+            logger.error(f"Face recognition failed: {e}")
+            return JSONResponse(status_code=500, content={'status': 2, 'message': "Internal server error"})
+
+    @router.post("/create_face_img_base64")
+    async def create_face_img_base64(data: CreateFace):
+        try:
+            return await face_service.create_face(data)
+        except Exception as e:
+            logger.error(f"Face creation failed: {e}", exc_info=True)
+            return JSONResponse(status_code=500, content={'status': 2, 'message': f"Internal server error: {e}"})
+
+    return router
+
+
+def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002) -> FastAPI:
+    """A FastAPI app serving the two routes from one GPU context with a loaded model."""
+    from . import legacy
+    from .batcher import EmbedBatcher
+    from .database_client import DatabaseClient
+    from .face_service import FaceService
+    from .gallery_service import GalleryService
+
+    batcher = EmbedBatcher(ctx, max_delay_s=max_delay_s)
+    legacy.install_engine(batcher)
+    service = GalleryService(ctx, capacity=capacity)
+    face_service = FaceService(DatabaseClient(service))
+    app = FastAPI(title="frhot recognition path")
+    app.include_router(build_router(face_service, api_key))
+    app.state.batcher = batcher
+    app.state.gallery_service = service
+    app.state.face_service = face_service
+
+    @app.on_event("shutdown")
+    def _shutdown():
+        batcher.close()
+        service.close()
+
+    return app

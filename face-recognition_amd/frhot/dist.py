@@ -1,0 +1,59 @@
+"""Row-sharded gallery search over torch.distributed (RCCL on GPUs, gloo in CPU tests).
+
+The path shards two ways: crops are split data-parallel (no collective: every rank
+embeds its own batch), and the gallery is split by rows (rank r holds global rows
+[row_base_r, row_base_r + rows_r)).  The two meet in one exchange per step:
+
+  1. all-gather the per-rank unit fp16 queries [B, D] -> [P*B, D];
+  2. every rank scans ITS shard with all P*B queries -> per-shard top-k with global rows;
+  3. all-gather the per-shard lists [P*B, k] -> [P, P*B, k];
+  4. merge the P lists of every query -> global top-k (same tie rule as one shard:
+     descending score, ascending row).
+
+The scan and the merge are callables so that the same orchestration runs on the
+HIP library (bench.py) and on a CPU stand-in (tests, gloo).
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedSearch:
+    def __init__(self, world: int, batch: int, dim: int, k: int, device,
+                 search_local: Callable, merge: Callable, qdtype=torch.float16):
+        """search_local(q_all, scores_out, rows_out): fill [P*B,k] float32 / int64 (global rows, -1 = none).
+        merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
+        self.P, self.B, self.D, self.k = world, batch, dim, k
+        self.search_local, self.merge = search_local, merge
+        n = world * batch
+        self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if world > 1 else None
+        self.s_local = torch.empty((n, k), dtype=torch.float32, device=device)
+        self.r_local = torch.empty((n, k), dtype=torch.int64, device=device)
+        if world > 1:
+            self.s_all = torch.empty((world, n, k), dtype=torch.float32, device=device)
+            self.r_all = torch.empty((world, n, k), dtype=torch.int64, device=device)
+            self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
+            self.out_r = torch.empty((n, k), dtype=torch.int64, device=device)
+
+    def __call__(self, q_local: torch.Tensor):
+        """q_local [B, D] unit rows of this rank -> (scores [P*B,k], rows [P*B,k]) for every rank's queries."""
+        if self.P == 1:
+            self.search_local(q_local, self.s_local, self.r_local)
+            return self.s_local, self.r_local
+        dist.all_gather_into_tensor(self.q_all, q_local)
+        self.search_local(self.q_all, self.s_local, self.r_local)
+        # the gather output is passed flat ([P*n, k], rank-major): gloo rejects the stacked shape
+        dist.all_gather_into_tensor(self.s_all.view(-1, self.k), self.s_local)
+        dist.all_gather_into_tensor(self.r_all.view(-1, self.k), self.r_local)
+        self.merge(self.s_all, self.r_all, self.out_s, self.out_r)
+        return self.out_s, self.out_r
+
+
+def shard_rows(total_rows: int, world: int, rank: int):
+    """Contiguous row split: (row_base, rows_local); the last ranks may hold one row fewer."""
+    per = (total_rows + world - 1) // world
+    base = min(rank * per, total_rows)
+    return base, max(0, min(per, total_rows - base))

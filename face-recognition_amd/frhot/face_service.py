@@ -1,0 +1,212 @@
+"""Drop-in for the recognise / enrol paths of the reference's FaceService
+(app/src/services/face_service.py:54-616): same coroutine names, same status
+codes and JSON bodies, with the embedding and the search served by libfrhot.so.
+
+Out of the recognition path and therefore not reproduced: face detection and the
+check-in quality gates (face_service.py:73-219), the anti-spoofing verdict and the
+MinIO image upload.  The service always takes the reference's `is_detect_face=False`
+branch (face_service.py:127-131): the whole decoded image is the face box.
+`image_sink`, if given, receives what the reference would hand to
+ImageProcessor.save_face_image.
+"""
+from __future__ import annotations
+
+import asyncio
+import base64
+import io
+import logging
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+from fastapi.responses import JSONResponse
+
+from .legacy import adjust_gamma, check_condition, get_embedding
+
+logger = logging.getLogger(__name__)
+
+HTTP_SEMAPHORE_LIMIT = 10        # face_service.py:42
+PROCESSING_SEMAPHORE_LIMIT = 10  # face_service.py:43
+
+
+def decode_image(img_base64: str) -> np.ndarray:
+    """base64 -> uint8 HxWx3 BGR (the reference uses cv2.imdecode(flags=-1), face_service.py:65-66)."""
+    from PIL import Image
+    contents = base64.b64decode(img_base64)
+    img = Image.open(io.BytesIO(contents))
+    img.load()
+    if img.mode not in ("RGB", "RGBA", "L"):
+        img = img.convert("RGB")
+    arr = np.asarray(img)
+    if arr.ndim == 2:
+        return arr
+    return np.ascontiguousarray(arr[:, :, :3][:, :, ::-1])
+
+
+class FaceService:
+    def __init__(self, database_client, image_sink=None):
+        self.database_client = database_client
+        self.image_sink = image_sink
+        self._http_sem = None
+        self._proc_sem = None
+        self._pool = ThreadPoolExecutor(max_workers=PROCESSING_SEMAPHORE_LIMIT, thread_name_prefix="frhot-embed")
+
+    def _sems(self):
+        if self._http_sem is None:
+            self._http_sem = asyncio.Semaphore(HTTP_SEMAPHORE_LIMIT)
+            self._proc_sem = asyncio.Semaphore(PROCESSING_SEMAPHORE_LIMIT)
+        return self._http_sem, self._proc_sem
+
+    async def _save(self, data, img, face_id, name, is_checkin=True):
+        if self.image_sink is not None:
+            await self.image_sink(data, img, face_id, name, is_checkin)
+
+    async def detect_and_embed_face(self, data, is_detect_face: bool = False,
+                                    is_checkin: bool = True) -> Tuple[bool, Any]:
+        """face_service.py:54-273 restricted to decode -> crop -> gamma -> embedding."""
+        _, proc = self._sems()
+        async with proc:
+            try:
+                img_decode = decode_image(data.img_base64)
+                img_size = img_decode.shape
+                boxes = [[0, 0, img_size[1], img_size[0]]]     # face_service.py:128-131
+                distances = [50]
+            except Exception as e:
+                logger.warning(f"{data.store_id} - Error when decoding image: {e}")
+                return False, JSONResponse(status_code=500, content={
+                    'status': 2, 'message': "Error when detecting face! Please try again"})
+            try:
+                idx_large = int(np.argmin(distances))
+                x, y, w, h = boxes[idx_large]
+                x1, y1, x2, y2 = int(x), int(y), int(x + w), int(y + h)
+                face = img_decode[y1:y2, x1:x2].astype('uint8')        # face_service.py:180-181
+                face = adjust_gamma(face, gamma=1.5)                   # face_service.py:223
+                try:
+                    loop = asyncio.get_running_loop()
+                    emb, is_real = await loop.run_in_executor(self._pool, lambda: get_embedding(face, img_decode))
+                    if not is_real and is_checkin:
+                        return False, JSONResponse(status_code=400, content={
+                            'status': 2, 'message': "Face is not real! Please use your real face"})
+                except Exception as e:
+                    logger.warning(f"{data.store_id} - Error when encoding face: {e}")
+                    return False, JSONResponse(status_code=500, content={
+                        'status': 2, 'message': "Error! Please try again"})
+                return True, (emb, img_decode)
+            except Exception as e:
+                logger.warning(f"{data.store_id} - Error in face processing: {e}")
+                return False, JSONResponse(status_code=500, content={
+                    'status': 2, 'message': "Error when processing face! Please try again"})
+
+    async def search_face(self, collection_name: str, embedding: List[float], store_id: str) -> Dict[str, Any]:
+        """face_service.py:275-308."""
+        http, _ = self._sems()
+        async with http:
+            try:
+                results = await self.database_client.search_point(
+                    collection_name=collection_name, vector_embedding=embedding, store_id=store_id)
+                if results:
+                    return {"message": "Point found", "data": [[r['score'], r['payload']] for r in results]}
+                return {"message": "Point not found", "data": []}
+            except Exception as e:
+                logger.error(f"Error in search_face: {e}")
+                return {"data": []}
+
+    def extract_face_info(self, search_result: Dict[str, Any]) -> Tuple[str, str, str]:
+        """face_service.py:310-330."""
+        try:
+            if not search_result or 'data' not in search_result or not search_result['data']:
+                return "Unknown", "Unknown", "Unknown"
+            item = search_result['data'][0]
+            if len(item) > 1 and isinstance(item[1], dict):
+                return (item[1].get('id', "Unknown"), item[1].get('name', "Unknown"),
+                        item[1].get('time_created', "Unknown"))
+            return "Unknown", "Unknown", "Unknown"
+        except Exception as e:
+            logger.error(f"Error extracting face info: {e}")
+            return "Unknown", "Unknown", "Unknown"
+
+    async def recognize_face(self, data) -> JSONResponse:
+        """face_service.py:332-477."""
+        img_decode = None
+        t0 = time.time()
+        try:
+            ok, message = check_condition(data, is_checkin=True)
+            if not ok:
+                return JSONResponse(status_code=400, content={'status': 2, 'message': message})
+            if data.role == '1':
+                collection_name, is_checkin = f'{data.store_id}_Employees', True
+            elif data.role == '0':
+                collection_name, is_checkin = f'{data.store_id}_Customers', False
+            else:
+                return JSONResponse(status_code=400, content={'status': 2, 'message': "Invalid role"})
+            collection_exists, (check_emb, message) = await asyncio.gather(
+                self.database_client.ensure_collections_exist(data.store_id),
+                self.detect_and_embed_face(data, is_checkin=is_checkin))
+            if not collection_exists:
+                return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when create collection"})
+            if not check_emb:
+                return message
+            emb, img_decode = message
+            if emb is None:
+                await self._save(data, img_decode, "Unknown", "Unknown")
+                return JSONResponse(status_code=200, content={'status': 1, 'id': "Unknown", 'name': "Unknown"})
+            search_result = await self.search_face(collection_name, emb, data.store_id)
+            face_id, name, _time_created = self.extract_face_info(search_result)
+            if face_id == "Unknown" and name == "Unknown":
+                return JSONResponse(status_code=404, content={
+                    'status': 0, 'message': "Face is not existed! Please register your face or checkin again"})
+            await self._save(data, img_decode, face_id, name)
+            logger.info(f"[TIMING] {data.store_id} - Total successful request time: {time.time() - t0:.3f}s")
+            return JSONResponse(status_code=200, content={'status': 1, 'id': face_id, 'name': name})
+        except Exception as e:
+            logger.error(f"recognize_face - {getattr(data, 'store_id', None)} - Error: {e}")
+            try:
+                if img_decode is not None:
+                    await self._save(data, img_decode, "Unknown", "Unknown")
+            except Exception as save_error:
+                logger.error(f"Failed to save image: {save_error}")
+            return JSONResponse(status_code=500, content={'status': 1, 'id': "Unknown", 'name': "Unknown"})
+
+    async def create_face(self, data, update_face=False) -> JSONResponse:
+        """face_service.py:479-616."""
+        if update_face or data.is_update:
+            data.is_update = True
+            verb = "update"
+        else:
+            verb = "create"
+        id_value, name_value, store_id = data.id, data.name, data.store_id
+        ok, message = check_condition(data, is_checkin=False)
+        if not ok:
+            return JSONResponse(status_code=400, content={'status': 2, 'message': message})
+        if data.role == '1':
+            collection_name = f'{store_id}_Employees'
+        elif data.role == '0':
+            collection_name = f'{store_id}_Customers'
+        else:
+            return JSONResponse(status_code=400, content={'status': 2, 'message': "Invalid role"})
+        collection_exists, (check_emb, message) = await asyncio.gather(
+            self.database_client.ensure_collections_exist(store_id),
+            self.detect_and_embed_face(data, is_checkin=False))
+        if not collection_exists:
+            return JSONResponse(status_code=500, content={'status': 2, 'message': "Error! Please try again"})
+        if not check_emb:
+            return message
+        emb, img_decode = message
+        if emb is None:
+            await self._save(data, img_decode, id_value, name_value, is_checkin=False)
+            return JSONResponse(status_code=200, content={
+                'status': 1, 'message': f'{verb} face {name_value} with id {id_value} successfully'})
+        if not data.is_update:
+            search_result = await self.search_face(collection_name, emb, store_id)
+            if search_result.get('data') and len(search_result['data']) > 0:
+                return JSONResponse(status_code=409, content={
+                    'status': 0, 'message': "Face is existed! Please use another face"})
+        success = await self.database_client.insert_point(
+            collection_name=collection_name, vector_embedding=emb, id=id_value, name=name_value,
+            store_id=store_id, is_update_id=False)
+        if not success:
+            return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when insert face"})
+        await self._save(data, img_decode, id_value, name_value, is_checkin=False)
+        return JSONResponse(status_code=201, content={
+            'status': 1, 'message': f'{verb} face {name_value} with id {id_value} successfully'})

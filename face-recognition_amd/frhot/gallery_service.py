@@ -1,0 +1,213 @@
+"""In-process replacement of the reference's DB service (qdrant_database_FE/app.py).
+
+Same operations, same status codes and JSON contents, but the points live in one
+device-resident gallery (frhot.engine.Gallery) instead of Qdrant collections:
+
+  * a collection name plus the payload's store_id intern to one int32 key per row,
+    so the reference's "collection + must store_id == value" filter
+    (qdrant_database_FE/app.py:316-327) is one key comparison inside the scan;
+  * the row -> (point id, payload) table, the <=10-faces-per-id eviction
+    (app.py:207-240), delete-by-payload-id (app.py:409-438) and the threshold + vote
+    (app.py:340-384) stay on the host.
+
+Methods return (status_code, content) exactly as the handlers answer.
+"""
+from __future__ import annotations
+
+import datetime
+import threading
+import uuid
+
+import numpy as np
+
+from .vote import vote
+
+DIM = 4096
+SEARCH_LIMIT = 5
+
+
+class GalleryService:
+    def __init__(self, ctx, capacity: int = 1 << 16, dim: int = DIM, gallery=None):
+        """`gallery`: an object with the upsert / tombstone / search / close methods of
+        frhot.engine.Gallery to use instead of creating one on `ctx` (tests inject a stand-in)."""
+        self.dim = dim
+        self.capacity = capacity
+        if gallery is None:
+            from .engine import Gallery
+            gallery = Gallery(ctx, dim, capacity)
+        self.gallery = gallery
+        self._lock = threading.RLock()
+        self._collections: dict[str, None] = {}
+        self._keys: dict[tuple, int] = {}          # (collection, store_id) -> device key
+        self._points: dict[int, dict] = {}         # row -> {"uid", "payload", "collection", "seq"}
+        self._by_id: dict[tuple, list] = {}        # (collection, payload id) -> rows in insertion order
+        self._free: list[int] = []
+        self._next_row = 0
+        self._seq = 0
+
+    def close(self):
+        self.gallery.close()
+
+    # ------------------------------------------------------------ collections
+    def get_collections(self):
+        """app.py:100-106."""
+        with self._lock:
+            return {"status": 200, "collections": list(self._collections)}
+
+    def collection_exists(self, name) -> bool:
+        with self._lock:
+            return name in self._collections
+
+    def create_collection(self, collection_name):
+        """app.py:108-128."""
+        if collection_name is None:
+            return 404, {"message": "Collection name not found!"}
+        with self._lock:
+            if collection_name not in self._collections:
+                self._collections[collection_name] = None
+                return 201, {"message": "Collection created"}
+            return 200, {"message": "Collection existed"}
+
+    def point_count(self, collection_name) -> int:
+        with self._lock:
+            return sum(1 for p in self._points.values() if p["collection"] == collection_name)
+
+    # ----------------------------------------------------------------- points
+    def _key(self, collection, store_id) -> int:
+        k = (collection, store_id)
+        if k not in self._keys:
+            self._keys[k] = len(self._keys)
+        return self._keys[k]
+
+    def _alloc_row(self) -> int:
+        if self._free:
+            return self._free.pop()
+        if self._next_row >= self.capacity:
+            raise MemoryError("gallery capacity exhausted")
+        r = self._next_row
+        self._next_row += 1
+        return r
+
+    def _drop_rows(self, rows):
+        if not rows:
+            return
+        self.gallery.tombstone(np.asarray(rows, dtype=np.int64))
+        for r in rows:
+            p = self._points.pop(r)
+            lst = self._by_id[(p["collection"], p["payload"]["id"])]
+            lst.remove(r)
+            if not lst:
+                del self._by_id[(p["collection"], p["payload"]["id"])]
+            self._free.append(r)
+
+    def _enforce_face_limit(self, collection, pid, limit=10):
+        """app.py:207-240: among the first limit+5 points of this id, delete the oldest so limit-1 stay."""
+        rows = list(self._by_id.get((collection, pid), []))[:limit + 5]
+        if len(rows) >= limit:
+            rows.sort(key=lambda r: (self._points[r]["payload"].get("time_created", ""), self._points[r]["seq"]))
+            self._drop_rows(rows[:len(rows) - limit + 1])
+
+    def insert_point(self, collection_name, vector_embedding, id, name, store_id, is_update_id=False,
+                     time_created=None):
+        """app.py:242-297."""
+        if time_created is None:
+            time_created = datetime.datetime.now().strftime("%Y/%m/%d %H:%M:%S")
+        if collection_name == "" or collection_name is None:
+            return 404, {"message": "Collection name not found or invalid!"}
+        with self._lock:
+            if collection_name not in self._collections:
+                return 404, {"message": "Collection name not found or invalid!"}
+            if vector_embedding is None or len(vector_embedding) != self.dim:
+                return 404, {"message": "Embedding not found or invalid!"}
+            if id is None or id == "":
+                return 404, {"message": "ID not found or invalid!"}
+            if name is None or id == "":
+                return 404, {"message": "Name not found or invalid!"}
+            try:
+                if not is_update_id:
+                    self._enforce_face_limit(collection_name, id, limit=10)
+            except Exception as e:  # the reference only logs this failure (app.py:271-272)
+                print(f"Error checking face limit: {e}")
+            payload = {'id': id, 'name': name, 'store_id': store_id, 'time_created': time_created}
+            try:
+                vec = np.asarray(vector_embedding, dtype=np.float32).reshape(1, self.dim)
+                if is_update_id:
+                    rows = self._by_id.get((collection_name, id))
+                    if not rows:
+                        return 404, {"message": "ID not found!"}
+                    row = rows[0]
+                    old = self._points[row]
+                    self.gallery.upsert(vec, self._key(collection_name, old["payload"].get("store_id")), [row])
+                    return 201, {"message": "Point inserted"}
+                row = self._alloc_row()
+                self.gallery.upsert(vec, self._key(collection_name, store_id), [row])
+                self._seq += 1
+                self._points[row] = {"uid": str(uuid.uuid4()), "payload": payload, "collection": collection_name,
+                                     "seq": self._seq}
+                self._by_id.setdefault((collection_name, id), []).append(row)
+                return 201, {"message": "Point inserted"}
+            except Exception as e:
+                return 404, {"message": str(e)}
+
+    def delete_point(self, collection_name, id):
+        """app.py:409-438."""
+        if collection_name is None or collection_name == "":
+            return 404, {"message": "Collection name not found or invalid!"}
+        with self._lock:
+            if collection_name not in self._collections:
+                return 404, {"message": "Collection name not found or invalid!"}
+            if id is None or id == "":
+                return 404, {"message": "ID not found or invalid!"}
+            try:
+                self._drop_rows(list(self._by_id.get((collection_name, id), [])))
+                return 200, {"message": "Point deleted"}
+            except Exception as e:
+                return 404, {"message": str(e)}
+
+    # ----------------------------------------------------------------- search
+    def _validate_search(self, collection_name, vector_embedding):
+        if collection_name is None or collection_name == "":
+            return 404, {"message": "Collection name not found or invalid!"}
+        if collection_name not in self._collections:
+            return 404, {"message": "Collection name not found or invalid!"}
+        if vector_embedding is None or len(vector_embedding) != self.dim:
+            return 404, {"message": "Embedding not found or invalid!"}
+        return None
+
+    def _hits(self, scores, rows):
+        out = []
+        for s, r in zip(scores, rows):
+            if r >= 0 and int(r) in self._points:
+                out.append((float(s), self._points[int(r)]["payload"]))
+        return out
+
+    def search_point(self, collection_name, vector_embedding, store_id):
+        """app.py:300-386."""
+        return self.search_points([(collection_name, vector_embedding, store_id)])[0]
+
+    def search_points(self, requests):
+        """Batched form: [(collection_name, vector, store_id)] -> [(status, content)], one device scan."""
+        with self._lock:
+            out = [None] * len(requests)
+            idx, vecs, keys = [], [], []
+            for i, (col, vec, store_id) in enumerate(requests):
+                bad = self._validate_search(col, vec)
+                if bad is not None:
+                    out[i] = bad
+                    continue
+                k = self._keys.get((col, store_id))
+                if k is None:           # nothing was ever stored under this collection + store
+                    out[i] = (200, {"message": "Point not found", "data": []})
+                    continue
+                idx.append(i)
+                vecs.append(np.asarray(vec, dtype=np.float32))
+                keys.append(k)
+            if idx:
+                try:
+                    scores, rows = self.gallery.search(np.stack(vecs), np.asarray(keys, np.int32), SEARCH_LIMIT)
+                    for j, i in enumerate(idx):
+                        out[i] = (200, vote(self._hits(scores[j], rows[j])))
+                except Exception as e:
+                    for i in idx:
+                        out[i] = (404, {"message": str(e)})
+            return out

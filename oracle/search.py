@@ -66,6 +66,27 @@ def cosine_topk(q, g, k, keys=None, qkeys=None, gallery_dtype=np.float32, chunk=
     return best_s.astype(np.float32), best_r
 
 
+def cosine_topk_fast(q, g_unit, k):
+    """Timing-oriented variant for the CPU baseline: g_unit is already unit float32 (as a
+    server would keep it); one BLAS product per chunk, argpartition, then an exact sort of
+    the k survivors.  Same scores as cosine_topk; tie order inside exact ties may differ."""
+    qn = unit_rows(q)
+    Bq, N = qn.shape[0], g_unit.shape[0]
+    best_s = np.full((Bq, 0), -np.inf, dtype=np.float32)
+    best_r = np.zeros((Bq, 0), dtype=np.int64)
+    chunk = 1 << 18
+    for lo in range(0, N, chunk):
+        s = qn @ g_unit[lo:lo + chunk].T
+        kk = min(k, s.shape[1])
+        idx = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+        cs = np.concatenate([best_s, np.take_along_axis(s, idx, axis=1)], axis=1)
+        cr = np.concatenate([best_r, idx.astype(np.int64) + lo], axis=1)
+        order = np.lexsort((cr, -cs), axis=1)[:, :k]
+        best_s = np.take_along_axis(cs, order, axis=1)
+        best_r = np.take_along_axis(cr, order, axis=1)
+    return best_s.astype(np.float32), best_r
+
+
 def vote(result):
     """qdrant_database_FE/app.py:340-384, literally.
 

@@ -1,0 +1,96 @@
+"""The N > 1 path on CPU: world_size-2 gloo run of the row-sharded search orchestration
+(all-gather queries -> local scan -> all-gather top-k -> merge) with the scan and merge
+played by the CPU oracle; the result must equal one exact search over the whole gallery."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, dim, batch, k, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "face-recognition_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frhot import synth
+        from frhot.dist import ShardedSearch, shard_rows
+        from oracle import search as osr
+        g = synth.unit_gallery(seed=123, n=n_rows, d=dim)
+        g[n_rows - 1] = g[0]                      # a tie that straddles the two shards
+        base, rows = shard_rows(n_rows, world, rank)
+        shard = g[base:base + rows]
+        rng = np.random.default_rng(1000 + rank)
+        targets = rng.integers(0, n_rows, size=batch)
+        q_local = synth.planted_queries(rng, g[targets], 0.8)
+        if rank == 0:
+            q_local[0] = g[0]                     # scores exactly 1.0 against rows 0 and n_rows-1
+
+        def search_local(q_all, s_out, r_out):
+            s, r = osr.cosine_topk(q_all.numpy(), shard, k)
+            r = np.where(r >= 0, r + base, -1)
+            s_out.copy_(torch.from_numpy(s))
+            r_out.copy_(torch.from_numpy(r))
+
+        def merge(s_all, r_all, out_s, out_r):
+            P, n, kk = s_all.shape
+            cs = s_all.permute(1, 0, 2).reshape(n, P * kk).numpy()
+            cr = r_all.permute(1, 0, 2).reshape(n, P * kk).numpy()
+            cs = np.where(cr < 0, -np.inf, cs)
+            crs = np.where(cr < 0, np.iinfo(np.int64).max, cr)
+            order = np.lexsort((crs, -cs), axis=1)[:, :kk]
+            out_s.copy_(torch.from_numpy(np.take_along_axis(cs, order, 1)))
+            out_r.copy_(torch.from_numpy(np.take_along_axis(cr, order, 1)))
+
+        ss = ShardedSearch(world, batch, dim, k, torch.device("cpu"), search_local, merge, qdtype=torch.float32)
+        s, r = ss(torch.from_numpy(q_local))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), q=q_local, targets=targets)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [1000, 1001])
+def test_sharded_search_equals_global_search(tmp_path, n_rows):
+    world, dim, batch, k = 2, 64, 6, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_rows, dim, batch, k, str(tmp_path)), nprocs=world, join=True)
+    from frhot import synth
+    from oracle import search as osr
+    g = synth.unit_gallery(seed=123, n=n_rows, d=dim)
+    g[n_rows - 1] = g[0]
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    q_all = np.concatenate([o["q"] for o in outs])
+    ref_s, ref_r = osr.cosine_topk(q_all, g, k)
+    for o in outs:                                  # every rank holds the full answer
+        assert np.array_equal(o["r"], ref_r)
+        assert np.abs(o["s"] - ref_s).max() < 1e-6
+    assert list(outs[0]["r"][0, :2]) == [0, n_rows - 1]          # tie ordered by ascending global row
+    targets = np.concatenate([o["targets"] for o in outs])
+    assert (ref_r[1:, 0] == targets[1:]).mean() > 0.8
+
+
+def test_shard_rows_cover_everything():
+    from frhot.dist import shard_rows
+    for total in (1, 7, 8, 1000, 10_000_000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_rows(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(n for _, n in spans) == total
+            for (b0, n0), (b1, _n1) in zip(spans, spans[1:]):
+                assert b1 == b0 + n0 or _n1 == 0

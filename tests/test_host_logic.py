@@ -1,0 +1,254 @@
+"""Host-side logic without a GPU: vote, gallery service bookkeeping, client reshaping,
+the two handlers' status table, weight blob, synthetic data, micro-batcher."""
+import asyncio
+import base64
+import io
+import itertools
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from fakes import HashEmbedder, NumpyGallery
+from oracle import search as osr
+
+
+# ------------------------------------------------------------------ vote ---
+def test_vote_equals_reference_restatement_exhaustively():
+    """Product vote == literal restatement of app.py:340-384 over every id pattern and a grid of scores."""
+    from frhot.vote import vote
+    score_sets = [
+        (0.9, 0.8, 0.7, 0.6, 0.55), (0.9, 0.8, 0.7, 0.5, 0.4), (0.6, 0.58, 0.57, 0.2, 0.1),
+        (0.56, 0.55, 0.53, 0.52, 0.5), (0.53, 0.5, 0.4, 0.3, 0.2), (0.54, 0.54, 0.54, 0.54, 0.54),
+        (0.9, 0.9, 0.6, 0.6, 0.1),
+    ]
+    n = 0
+    for scores in score_sets:
+        for length in range(0, 6):
+            for ids in itertools.product("ABC", repeat=length):
+                hits = [(scores[i], {"id": ids[i], "name": ids[i], "slot": i}) for i in range(length)]
+                assert vote(hits) == osr.vote(hits), (scores, ids)
+                n += 1
+    assert n > 2000
+
+
+# ------------------------------------------------------- gallery service ---
+def _service(dim=16, capacity=64):
+    from frhot.gallery_service import GalleryService
+    return GalleryService(None, capacity=capacity, dim=dim, gallery=NumpyGallery(dim, capacity))
+
+
+def test_gallery_service_matches_oracle_collections_on_random_traffic():
+    rng = np.random.default_rng(0)
+    dim = 16
+    svc, ref = _service(dim, 256), osr.Collections(dim=dim)
+    cols = ["S1_Employees", "S1_Customers", "S2_Employees"]
+    for c in cols:
+        assert svc.create_collection(c) == ref.create_collection(c)
+    assert svc.create_collection(cols[0]) == ref.create_collection(cols[0]) == (200, {"message": "Collection existed"})
+    assert svc.create_collection(None) == ref.create_collection(None)
+    base = rng.normal(size=(6, dim)).astype(np.float32)
+    t = 0
+    for step in range(400):
+        op = rng.integers(0, 10)
+        col = cols[rng.integers(0, 3)]
+        store = col.split("_")[0] if rng.random() < 0.9 else "OTHER"
+        pid = "ABCDEF"[rng.integers(0, 6)]
+        vec = base["ABCDEF".index(pid)] + 0.25 * rng.normal(size=dim).astype(np.float32)
+        if op < 5:
+            t += 1
+            ts = f"2025/01/01 00:{t // 60:02d}:{t % 60:02d}"
+            a = svc.insert_point(col, vec, pid, "n" + pid, store, time_created=ts)
+            b = ref.insert_point(col, vec, pid, "n" + pid, store, ts)
+            assert a == b
+        elif op < 6:
+            assert svc.delete_point(col, pid) == ref.delete_point(col, pid)
+        else:
+            a = svc.search_point(col, vec, store)
+            b = ref.search_point(col, vec, store)
+            assert a[0] == b[0] and a[1]["message"] == b[1]["message"], (step, a, b)
+            if a[1]["data"]:
+                (sa, pa), (sb, pb) = a[1]["data"][0], b[1]["data"][0]
+                assert pa == pb and abs(sa - sb) < 1e-5
+        for c in cols:
+            assert svc.point_count(c) == len(ref.cols[c])
+    # nobody holds more than 10 faces per id in a collection
+    for c in cols:
+        for pid in "ABCDEF":
+            assert sum(1 for p in ref.cols[c] if p[2]["id"] == pid) <= 10
+
+
+def test_gallery_service_validation_and_eviction_order():
+    svc = _service(8, 64)
+    v = np.ones(8, np.float32)
+    assert svc.insert_point("", v, "A", "a", "S")[0] == 404
+    assert svc.insert_point("nope", v, "A", "a", "S") == (404, {"message": "Collection name not found or invalid!"})
+    svc.create_collection("S_Employees")
+    assert svc.insert_point("S_Employees", np.ones(7), "A", "a", "S") == (404, {"message": "Embedding not found or invalid!"})
+    assert svc.insert_point("S_Employees", v, "", "a", "S") == (404, {"message": "ID not found or invalid!"})
+    assert svc.insert_point("S_Employees", v, "A", "a", "S", is_update_id=True) == (404, {"message": "ID not found!"})
+    for i in range(13):
+        assert svc.insert_point("S_Employees", v, "A", "a", "S", time_created=f"t{i:02d}") == (201, {"message": "Point inserted"})
+    times = sorted(p["payload"]["time_created"] for p in svc._points.values())
+    assert times == [f"t{i:02d}" for i in range(3, 13)]          # oldest evicted, 10 remain
+    assert svc.search_point("S_Employees", np.ones(3), "S")[0] == 404
+    assert svc.search_point("", v, "S")[0] == 404
+    assert svc.search_point("S_Employees", v, "ELSEWHERE") == (200, {"message": "Point not found", "data": []})
+    assert svc.delete_point("S_Employees", "A") == (200, {"message": "Point deleted"})
+    assert svc.point_count("S_Employees") == 0 and len(svc._free) == 13 or len(svc._free) >= 10
+    assert svc.delete_point("S_Employees", None)[0] == 404
+    # freed rows are reused
+    svc.insert_point("S_Employees", v, "B", "b", "S")
+    assert svc._next_row <= 13
+
+
+def test_database_client_reshapes_like_the_reference():
+    from frhot.database_client import DatabaseClient
+    svc = _service(8, 32)
+    cli = DatabaseClient(svc)
+
+    async def run():
+        assert await cli.ensure_collections_exist("S9") is True
+        assert svc.collection_exists("S9_Customers") and svc.collection_exists("S9_Employees")
+        v = [1.0] + [0.0] * 7
+        assert await cli.insert_point("S9_Employees", v, "7", "Sev", "S9") is True
+        assert await cli.insert_point("missing", v, "7", "Sev", "S9") is False
+        res = await cli.search_point("S9_Employees", v, "S9")
+        assert len(res) == 1 and res[0]["id"] == "7" and res[0]["payload"]["name"] == "Sev" and res[0]["score"] > 0.99
+        assert await cli.search_point("missing", v, "S9") == []          # every failure -> []
+        assert await cli.search_point("S9_Employees", [0.0] * 7 + [1.0], "S9") == []
+        assert await cli.delete_point("S9_Employees", "7") is True
+        assert await cli.search_point("S9_Employees", v, "S9") == []
+        assert await cli.delete_point("missing", "7") is False
+    asyncio.run(run())
+
+
+# --------------------------------------------------------------- handlers ---
+def _b64(img):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img[:, :, ::-1]).save(buf, format="PNG")
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+@pytest.fixture()
+def client():
+    from fastapi import FastAPI
+    from fastapi.testclient import TestClient
+    from frhot import legacy
+    from frhot.api import build_router
+    from frhot.database_client import DatabaseClient
+    from frhot.face_service import FaceService
+    legacy.install_engine(HashEmbedder())
+    svc = _service(4096, 64)
+    app = FastAPI()
+    app.include_router(build_router(FaceService(DatabaseClient(svc)), api_key="k"))
+    with TestClient(app) as c:
+        c.svc = svc
+        yield c
+    legacy.install_engine(None)
+
+
+def test_handlers_status_table(client):
+    from frhot import synth
+    rng = np.random.default_rng(1)
+    ann, bob = _b64(synth.crop(rng, 90, 80)), _b64(synth.crop(rng, 70, 100))
+    H = {"X-API-Key": "k"}
+    r = client.post("/face_recog_img_base64", json={"img_base64": ann, "role": "1", "store_id": "T"})
+    assert r.status_code == 403                                            # routes.py:21-28
+    r = client.post("/face_recog_img_base64", json={"img_base64": ann, "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 404 and r.json() == {
+        "status": 0, "message": "Face is not existed! Please register your face or checkin again"}
+    assert client.svc.collection_exists("T_Employees") and client.svc.collection_exists("T_Customers")
+    # enrol: validation table (legacy.py:278-292)
+    for body, msg in [({"img_base64": ann, "id": "", "name": "Ann", "role": "1", "store_id": "T"}, "id and name are required"),
+                      ({"img_base64": "", "id": "1", "name": "Ann", "role": "1", "store_id": "T"}, "invalid"),
+                      ({"img_base64": ann, "id": "1", "name": "Ann", "role": "5", "store_id": "T"}, "invalid"),
+                      ({"img_base64": ann, "id": "1", "name": "Ann", "role": "1", "store_id": ""}, "store_id is required")]:
+        r = client.post("/create_face_img_base64", json=body, headers=H)
+        assert r.status_code == 400 and r.json() == {"status": 2, "message": msg}
+    r = client.post("/create_face_img_base64", json={"img_base64": ann, "id": "345", "name": "Ann", "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 201 and r.json() == {"status": 1, "message": "create face Ann with id 345 successfully"}
+    r = client.post("/create_face_img_base64", json={"img_base64": ann, "id": "999", "name": "Dup", "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 409 and r.json() == {"status": 0, "message": "Face is existed! Please use another face"}
+    r = client.post("/create_face_img_base64", json={"img_base64": ann, "id": "345", "name": "Ann", "role": "1", "store_id": "T", "is_update": True}, headers=H)
+    assert r.status_code == 201 and r.json()["message"] == "update face Ann with id 345 successfully"
+    # recognise: the enrolled face, a stranger, another collection, another store
+    r = client.post("/face_recog_img_base64", json={"img_base64": ann, "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 200 and r.json() == {"status": 1, "id": "345", "name": "Ann"}
+    r = client.post("/face_recog_img_base64", json={"img_base64": bob, "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 404
+    r = client.post("/face_recog_img_base64", json={"img_base64": ann, "role": "0", "store_id": "T"}, headers=H)
+    assert r.status_code == 404                                            # Customers collection is empty
+    r = client.post("/face_recog_img_base64", json={"img_base64": ann, "role": "1", "store_id": "U"}, headers=H)
+    assert r.status_code == 404
+    r = client.post("/face_recog_img_base64", json={"img_base64": "", "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 400 and r.json() == {"status": 2, "message": "invalid"}
+    r = client.post("/face_recog_img_base64", json={"img_base64": "not-an-image", "role": "1", "store_id": "T"}, headers=H)
+    assert r.status_code == 500 and r.json()["status"] == 2
+
+
+# ------------------------------------------------------- weights / synth ---
+def test_weight_blob_layout(weights_f32):
+    from frhot.weights import LAYERS, MAGIC, pack_blob, quantize_fp16
+    blob = pack_blob(weights_f32)
+    assert bytes(blob[:8]) == MAGIC
+    version, count = struct.unpack("<II", bytes(blob[8:16]))
+    assert version == 1 and count == 2 * len(LAYERS)
+    entries = {}
+    for i in range(count):
+        name, dtype, ndim, d0, d1, d2, d3, off, nbytes = struct.unpack("<16sII4IQQ", bytes(blob[16 + 56 * i:16 + 56 * (i + 1)]))
+        entries[name.rstrip(b"\0").decode()] = (dtype, ndim, (d0, d1, d2, d3), off, nbytes)
+        assert off % 64 == 0 and off + nbytes <= blob.size
+    dt, nd, dims, off, nb = entries["conv3_2.w"]
+    assert (dt, nd, dims, nb) == (0, 4, (256, 3, 3, 256), 256 * 9 * 256 * 2)
+    w = blob[off:off + nb].view(np.float16).reshape(256, 3, 3, 256)
+    assert np.array_equal(w.astype(np.float32), quantize_fp16(weights_f32)["conv3_2.w"])
+    dt, nd, dims, off, nb = entries["fc7.b"]
+    assert (dt, nd, dims[0], nb) == (1, 1, 4096, 4096 * 4)
+    assert entries["fc6.w"][2] == (4096, 7, 7, 512) and entries["fc7.w"][2][:2] == (4096, 4096)
+    conv_w = sum(int(np.prod(weights_f32[n + ".w"].shape)) for n, *_ in LAYERS[:13])
+    conv_b = sum(int(weights_f32[n + ".b"].size) for n, *_ in LAYERS[:13])
+    assert conv_w + conv_b == 14_714_688
+    assert weights_f32["fc6.w"].size + 4096 == 102_764_544 and weights_f32["fc7.w"].size + 4096 == 16_781_312
+
+
+def test_synth_is_deterministic_and_packs():
+    from frhot import synth
+    a, b = synth.crops(5, 3, 40, 60), synth.crops(5, 3, 40, 60)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    buf, off, hw, st = synth.pack_crops(a)
+    for im, o, (h, w), s in zip(a, off, hw, st):
+        assert s == 3 * w and np.array_equal(buf[o:o + h * w * 3].reshape(h, w, 3), im) and o % 16 == 0
+    g = synth.unit_gallery(1, 50, 64, sparse=True)
+    assert np.allclose(np.linalg.norm(g, axis=1), 1, atol=1e-5) and (g >= 0).all()
+    q = synth.planted_queries(np.random.default_rng(0), g[:10], 0.8)
+    cos = (q * g[:10]).sum(1)
+    assert 0.6 < cos.mean() < 0.95
+
+
+def test_micro_batcher_groups_concurrent_callers():
+    from frhot.batcher import EmbedBatcher
+
+    class Ctx:
+        max_batch = 8
+        sizes = []
+
+        def embed(self, images, gamma=False):
+            self.sizes.append(len(images))
+            return np.stack([np.full(4096, float(im[0, 0, 0]) + (100 if gamma else 0), np.float32) for im in images])
+
+    ctx = Ctx()
+    b = EmbedBatcher(ctx, max_delay_s=0.05)
+    out = {}
+
+    def call(i):
+        out[i] = b.embed(np.full((4, 4, 3), i, np.uint8), gamma=(i % 2 == 1))
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(20)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    b.close()
+    for i in range(20):
+        assert out[i][0] == i + (100 if i % 2 else 0)
+    assert sum(ctx.sizes) == 20 and max(ctx.sizes) <= 8 and len(ctx.sizes) < 20
