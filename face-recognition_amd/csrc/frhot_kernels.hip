@@ -14,9 +14,26 @@
 // ds_read_b128, v_mfma_f32_16x16x32_f16 accumulation in fp32.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "frhot_kernels.h"
 
+#ifndef FR_DBG
+#define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps
+#endif
+
 namespace frhot {
+
+#if FR_DBG & 8
+__device__ unsigned long long g_stamp[64];
+#define FR_STAMP(var)                                                                        \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define FR_STAMP(var) do { } while (0)
+#endif
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -24,6 +41,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 #define FR_DEV __device__ __forceinline__
+
 
 // ---------------------------------------------------------------- helpers ---
 FR_DEV void glds16(const void* g, void* lds_wave_base) {
@@ -733,6 +751,321 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     }
 }
 
+// 3x3 convolution with the input PATCH resident in LDS (layers whose height is a multiple
+// of 16).  A tile is 16x16 output pixels of one image by RY channels.  Its 18x18-pixel input
+// patch (one 64-channel chunk: 324 x 128 B, 41 one-KiB pieces) is fetched ONCE and read by
+// all nine taps, so the LDS fill traffic per tile is 1.27 x the tile's input instead of 9 x.
+// Item = (tile, 64-channel chunk), nine steps (taps) each; while an item computes, the next
+// item's patch streams into the other of two patch slots (one piece per wave in taps 0..5).
+// Weights: a ring of four RY x 128-B stages fetched three steps ahead, or, when all 9*CIN/64
+// stages fit beside the patches (CIN = COUT = 64), loaded once and kept (RES).
+//
+// Patch image in LDS: pixel P = py*18 + px owns the 128-B row P; 16-B chunk c of that row is
+// stored at chunk position c ^ sigma(px,py), sigma = ((px>>1)&3)<<1 | (py&1).  An MFMA B
+// fragment covers a 2x8-pixel block (lane&15 -> dy = (l>>1)&1, dx = 2*(l>>2) + (l&1)), and with
+// this sigma every 16-lane group of a ds_read_b128 touches 16 different 16-B slots of the
+// 256-B bank row for every tap shift.
+template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __restrict__ x,
+                                                            const half_t* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            half_t* __restrict__ y, half_t* __restrict__ dump,
+                                                            int batch) {
+    static_assert(WX * WY == 8 && HW % 16 == 0 && CIN % 64 == 0 && COUT % RY == 0 && RY % 64 == 0, "shape");
+    constexpr int PW = 18, NPIECE = 41, PATCH_B = NPIECE * 1024;
+    constexpr int CPK = CIN / 64, NKS = 9 * CPK, K = 9 * CIN;
+    constexpr int NT = COUT / RY;
+    constexpr int TX = 256 / WX, TY = RY / WY, NX = TX / 16, NY = TY / 16;
+    constexpr int YB = RY * 128, NPY = RY / 64;
+    constexpr bool RES = (NKS * YB + 2 * PATCH_B) <= 160 * 1024;
+    constexpr int WS = RES ? NKS : 4;
+    constexpr int TPR = HW / 16, TPI = TPR * TPR;   // tiles per row / per image
+    constexpr int IW = HW + 2;
+    constexpr int NCH = NX * NY / 2;                // epilogue chunks (one 16-B store each) per wave and tile
+    static_assert(NX % 2 == 0 && NY % 2 == 0 && NCH <= 18, "wave tile");
+    static_assert(2 * (NPY + 1) + 4 <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const patch = smem;
+    char* const wring = smem + 2 * PATCH_B;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = wave / WY, wy = wave % WY;
+    const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+    const long ntiles = (long)batch * TPI * NT;
+    const int G = gridDim.x;
+    const int wk = xcd_remap(blockIdx.x, G);
+    const long my_tiles = wk < ntiles ? (ntiles - wk + G - 1) / G : 0;
+    if (my_tiles == 0) return;
+    const long n_items = my_tiles * CPK;
+    const long S = n_items * 9;
+    const int n0 = (wk % NT) * RY;       // G is a multiple of NT: the channel tile never changes
+
+    // ---- staging addresses -------------------------------------------------------------
+    // patch piece j = min(8*t + wave, 40) in tap t < 6; this lane fetches 16 B of pixel 8j + lane/8
+    int poff[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        int j = 8 * t + wave;
+        j = j < NPIECE ? j : NPIECE - 1;
+        int P = 8 * j + (lane >> 3);
+        P = P < PW * PW ? P : PW * PW - 1;
+        const int py = P / PW, px = P - py * PW;
+        const int sig = (((px >> 1) & 3) << 1) | (py & 1);
+        poff[t] = ((py * IW + px) * CIN) * 2 + ((l7 ^ sig) << 4);
+    }
+    auto item_src = [&](long item) -> const char* {
+        const long tile = wk + (item / CPK) * G;
+        const int c = (int)(item % CPK);
+        const long st = tile / NT;
+        const int b = (int)(st / TPI), rem = (int)(st % TPI);
+        const int ty = rem / TPR, tx = rem - ty * TPR;
+        return (const char*)x + ((((long)b * IW + ty * 16) * IW + tx * 16) * CIN + c * 64) * 2;
+    };
+    auto issue_patch = [&](const char* src, int slot, int t) {
+        int j = 8 * t + wave;
+        j = j < NPIECE ? j : NPIECE - 1;
+        glds16(src + poff[t], patch + slot * PATCH_B + j * 1024);
+    };
+    // weight rows: LDS row r of a stage holds channel n0 + chan(r), permuted as in the ring
+    // kernel so that a lane's accumulators of a channel-tile pair are 8 consecutive channels
+    const int cb = ((l7 ^ (lane >> 3)) << 4);
+    const char* yp[NPY];
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+        const int r = 8 * (wave + 8 * i) + (lane >> 3);
+        const int in = r % TY, cy = in >> 4, g = (in >> 2) & 3, j = in & 3;
+        const int ch = (r / TY) * TY + (cy >> 1) * 32 + g * 8 + (cy & 1) * 4 + j;
+        yp[i] = (const char*)w + ((long)(n0 + ch) * K) * 2 + cb;
+    }
+    auto issue_w = [&](int stage, int ks) {     // ks = chunk*9 + tap
+        const int c = ks / 9, t = ks - c * 9;
+        const size_t off = ((size_t)t * CIN + c * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < NPY; ++i) glds16(yp[i] + off, wring + stage * YB + (wave + 8 * i) * 1024);
+    };
+
+    float4v bv[NY];
+#pragma unroll
+    for (int cy = 0; cy < NY; ++cy) {
+        bv[cy] = *(const float4v*)(bias + n0 + wy * TY + (cy >> 1) * 32 + g0 * 8 + (cy & 1) * 4);
+        asm volatile("" ::"v"(bv[cy][0]), "v"(bv[cy][1]), "v"(bv[cy][2]), "v"(bv[cy][3]));
+    }
+
+    // ---- fragment read addresses --------------------------------------------------------
+    // pixel of this lane inside a 2x8 block, block a = wx*NX + xi at rows 2*(a>>1), columns 8*(a&1)
+    const int dy = (l15 >> 1) & 1, dx = 2 * (l15 >> 2) + (l15 & 1);
+    const int lane_px = ((wx * NX / 2) * 2 * PW + dy * PW + dx) * 128;
+    // sigma of (px0 + s, py0 + r): column part per s, row part dy ^ (r & 1)
+    int sgx[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) sgx[s3] = (((dx + s3) >> 1) & 3) << 5;
+    const int wrow = (wy * TY + l15) * 128;
+
+    // acc: the tile being accumulated; accp: the finished tile before it, whose epilogue
+    // (bias, ReLU, pooling, fp16, store) is spread over the MFMA blocks of the current tile so
+    // that its vector work hides behind them instead of stalling every wave at the tile seam.
+    float4v acc[NY][NX], accp[NY][NX];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < NY; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < NX; ++b2) acc[a][b2] = float4v{0.f, 0.f, 0.f, 0.f};
+    };
+    zero();
+    constexpr int HO = POOL ? HW / 2 : HW, OW = HO + 2;
+    half_t* pend = dump + lane * 8;     // where chunk stores of the pending tile go; dump: no tile pending
+    long pend_stride_on = 0;            // 1 once a real tile is pending (0 keeps every chunk inside dump)
+    auto tile_out = [&](long tile) -> half_t* {
+        const long st = tile / NT;
+        const int b = (int)(st / TPI), rem = (int)(st % TPI);
+        const int ty = rem / TPR, tx = rem - ty * TPR;
+        const int a0 = wx * NX;
+        int oy, ox;
+        if (POOL) { oy = ty * 8 + (a0 >> 1); ox = tx * 8 + (l15 >> 2); }
+        else { oy = ty * 16 + 2 * (a0 >> 1) + dy; ox = tx * 16 + dx; }
+        return y + (((long)b * OW + oy + 1) * OW + ox + 1) * COUT + n0 + wy * TY + g0 * 8;
+    };
+    auto quad_max = [&](float v) -> float {
+        // max over the 2x2 window = the four lanes of a quad (row-local DPP, no LDS traffic)
+        int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);   // lanes ^1
+        v = fmaxf(v, __builtin_bit_cast(float, t));
+        t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);       // lanes ^2
+        return fmaxf(v, __builtin_bit_cast(float, t));
+    };
+    auto epi_chunk = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < NCH) {
+            constexpr int b2 = j / (NY / 2), u = j % (NY / 2);
+            constexpr long boff = POOL ? ((long)(b2 >> 1) * OW + 4 * (b2 & 1)) * COUT
+                                       : ((long)2 * (b2 >> 1) * OW + 8 * (b2 & 1)) * COUT;
+            half8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4v v = accp[2 * u + h][b2];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float t2 = POOL ? quad_max(v[jj]) : v[jj];
+                    o[4 * h + jj] = (half_t)fmaxf(t2 + bv[2 * u + h][jj], 0.f);
+                }
+            }
+#if !(FR_DBG & 1)
+            if (!POOL || (lane & 3) == 0) *(half8*)(pend + (boff + u * 32) * pend_stride_on) = o;
+#else
+            asm volatile("" ::"v"(o), "v"(pend));
+#endif
+        }
+    };
+
+    half8 fxA[NX], fyA[NY], fxB[NX], fyB[NY];
+    auto load_frags = [&](auto tapc, auto kkc, int chunk, long s, const char* pb, half8 (&fx)[NX], half8 (&fy)[NY]) {
+        constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+        constexpr int r = tap / 3, sx = tap - 3 * r;
+        const char* const wb = wring + (RES ? (chunk * 9 + tap) : (int)(s & 3)) * YB;
+        const int wc = (((kk * 4 + g0) ^ l7) << 4);
+#pragma unroll
+        for (int a = 0; a < NY; ++a) fy[a] = *(const half8*)(wb + wrow + a * 16 * 128 + wc);
+        const int pc = ((kk * 64 + (g0 << 4)) ^ sgx[sx] ^ ((dy ^ (r & 1)) << 4));
+#pragma unroll
+        for (int b2 = 0; b2 < NX; ++b2) {
+            const int blk = (((b2 >> 1) * 2 + r) * PW + 8 * (b2 & 1) + sx) * 128;
+            fx[b2] = *(const half8*)(pb + lane_px + blk + pc);
+        }
+    };
+    auto mma = [&](const half8 (&fx)[NX], const half8 (&fy)[NY]) {
+#if FR_DBG & 4
+        asm volatile("" ::"v"(fx[0]), "v"(fx[NX - 1]), "v"(fy[0]), "v"(fy[NY - 1]));
+        return;
+#endif
+#pragma unroll
+        for (int a = 0; a < NY; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < NX; ++b2)
+                acc[a][b2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[a], fx[b2], acc[a][b2], 0, 0, 0);
+    };
+
+    // ---- prologue -------------------------------------------------------------------------
+    {
+        const char* src0 = item_src(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) issue_patch(src0, 0, t);
+        if (RES) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) issue_w(ks, ks);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                if (ks < S) issue_w(ks, ks % NKS);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    long s = 0;            // global step
+    int wks = 3 % NKS;     // ks of the weight stage issued next (non-resident)
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, sum_main = 0, sum_epi = 0, sum_bar = 0;
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)sum_main; (void)sum_epi; (void)sum_bar;
+    for (long item = 0; item < n_items; ++item) {
+        FR_STAMP(st0);
+        const int slot = (int)(item & 1);
+        const int chunk = (int)(item % CPK);
+        // the item after the last re-fetches the last item's patch into the idle slot: every
+        // step then issues the same number of loads, which the counted waits rely on
+        const char* nsrc = item_src(item + 1 < n_items ? item + 1 : item);
+        const char* const pb = patch + slot * PATCH_B;
+        auto step = [&](auto tapc) {
+            constexpr int tap = decltype(tapc)::value;
+            if (!RES) {
+                if (s + 3 < S) { issue_w((int)((s + 3) & 3), wks); wks = wks + 1 == NKS ? 0 : wks + 1; }
+            }
+#if !(FR_DBG & 2)
+            if (tap < 6) issue_patch(nsrc, slot ^ 1, tap);
+#endif
+            // fragment sets A (kk = 0) and B (kk = 1): the reads of one set are in flight while
+            // the MFMAs of the other run; with resident weights the next tap's set A is fetched
+            // before this tap's second MFMA block (nothing separates the taps of an item)
+            if (!RES || tap == 0) load_frags(tapc, std::integral_constant<int, 0>{}, chunk, s, pb, fxA, fyA);
+            // (the waits are written out so that each sits BEFORE the next set's reads are issued:
+            // left to the compiler they land after them, as lgkmcnt(0), and serialise the two)
+            __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): set A has landed
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(tapc, std::integral_constant<int, 1>{}, chunk, s, pb, fxB, fyB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fxA, fyA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk == 0) epi_chunk(std::integral_constant<int, 2 * tap>{});
+            __builtin_amdgcn_s_waitcnt(0xC07F);     // set B has landed
+            __builtin_amdgcn_sched_barrier(0);
+            if (RES && tap < 8)
+                load_frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, std::integral_constant<int, 0>{}, chunk,
+                           s, pb, fxA, fyA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fxB, fyB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk == 0) epi_chunk(std::integral_constant<int, 2 * tap + 1>{});
+            const bool tile_end = (tap == 8) && (chunk == CPK - 1);
+            if (tap == 8) FR_STAMP(st1);
+            if (tile_end) {
+#pragma unroll
+                for (int a = 0; a < NY; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < NX; ++b2) accp[a][b2] = acc[a][b2];
+                pend = tile_out(wk + (item / CPK) * G);
+                pend_stride_on = 1;
+                zero();
+            }
+            if (tap == 8) FR_STAMP(st2);
+            // ---- end of step: what may stay in flight ---------------------------------------
+            if (RES) {
+                // only the item's last step needs anything: the next patch and the pending tile's
+                // stores were all issued at least three steps ago
+                if (tap == 8) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                // everything issued before step s-1 must have landed (weights of step s+1 and,
+                // at tap 8, the next patch); the loads and epilogue stores of steps s-1 and s
+                // stay in flight.  Per step: NPY weight pieces, one patch piece in taps 0..5 and,
+                // in a tile's first item, the stores of epilogue chunks 2*tap and 2*tap+1.
+                constexpr int l_prev = NPY + ((tap + 8) % 9 < 6 ? 1 : 0), l_cur = NPY + (tap < 6 ? 1 : 0);
+                constexpr int e_prev = tap == 0 ? 0 : (2 * (tap - 1) < NCH) + (2 * (tap - 1) + 1 < NCH);
+                constexpr int e_cur = (2 * tap < NCH) + (2 * tap + 1 < NCH);
+                if (s + 4 >= S) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (chunk == 0) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l_prev + l_cur + e_prev + e_cur) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l_prev + l_cur) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+            ++s;
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+        FR_STAMP(st3);
+#if FR_DBG & 8
+        sum_main += st1 - st0; sum_epi += st2 - st1; sum_bar += st3 - st2;
+#endif
+    }
+    // epilogue of the last tile
+    epi_chunk(std::integral_constant<int, 0>{}); epi_chunk(std::integral_constant<int, 1>{});
+    epi_chunk(std::integral_constant<int, 2>{}); epi_chunk(std::integral_constant<int, 3>{});
+    epi_chunk(std::integral_constant<int, 4>{}); epi_chunk(std::integral_constant<int, 5>{});
+    epi_chunk(std::integral_constant<int, 6>{}); epi_chunk(std::integral_constant<int, 7>{});
+    static_assert(NCH <= 8, "flush list");
+#if FR_DBG & 8
+    if (blockIdx.x == 0 && lane == 0) {
+        g_stamp[wave * 4 + 0] = sum_main; g_stamp[wave * 4 + 1] = sum_epi; g_stamp[wave * 4 + 2] = sum_bar;
+        g_stamp[wave * 4 + 3] = (unsigned long long)n_items;
+    }
+#endif
+}
+
 // Gallery scan, 8 waves: gallery tile 256 rows (MFMA A operand), query tile RY in
 // {64,128,256} (B operand, one query per lane & 15).  The 1-D grid holds nb gallery
 // walkers per query tile; walker gb visits gallery tiles gb, gb+nb, ...  Blocks that
@@ -938,6 +1271,26 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
 // ---------------------------------------------------------------- launch ---
 #define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
+template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY>
+static hipError_t launch_patch_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
+                                    hipStream_t s, bool set_attr_only) {
+    auto kern = conv3x3_patch_kernel<HW, CIN, COUT, POOL, RY, WX, WY>;
+    constexpr int patch2 = 2 * 41 * 1024, nks = 9 * CIN / 64, yb = RY * 128;
+    constexpr bool res = nks * yb + patch2 <= 160 * 1024;
+    constexpr int lds = patch2 + (res ? nks : 4) * yb;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (set_attr_only)
+        return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    constexpr int NT = COUT / RY;
+    const long ntiles = (long)B * (HW / 16) * (HW / 16) * NT;
+    long grid = 256;                       // one walker per CU; a multiple of COUT / RY
+    if (grid > ntiles) grid = ntiles;      // ntiles is a multiple of NT
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
+                       (half_t*)y, (half_t*)dump, B);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
 template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RY, int WX, int WY>
 static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
                                    hipStream_t s, bool set_attr_only) {
@@ -961,9 +1314,13 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
 #define FR_CONV(HW, CIN, COUT, POOL, OPAD, RY, WX, WY)                                                       \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD)           \
         return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>(x, w, bias, y, dump, B, s, attr);
-    FR_CONV(224, 64, 64, true, 1, 64, 4, 2)
-    FR_CONV(112, 64, 128, false, 1, 128, 4, 2)
-    FR_CONV(112, 128, 128, true, 1, 128, 4, 2)
+#define FR_PATCH(HW, CIN, COUT, POOL, RY, WX, WY)                                                            \
+    if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == 1)              \
+        return launch_patch_inst<HW, CIN, COUT, POOL, RY, WX, WY>(x, w, bias, y, dump, B, s, attr);
+    FR_PATCH(224, 64, 64, true, 64, 4, 2)
+    FR_PATCH(112, 64, 128, false, 128, 4, 2)
+    FR_PATCH(112, 128, 128, true, 128, 4, 2)
+#undef FR_PATCH
     FR_CONV(56, 128, 256, false, 1, 256, 2, 4)
     FR_CONV(56, 256, 256, false, 1, 256, 2, 4)
     FR_CONV(56, 256, 256, true, 1, 256, 2, 4)

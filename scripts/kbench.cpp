@@ -1,0 +1,192 @@
+// Kernel micro-benchmark for libfrhot's HIP kernels (developer tool, not part of the library).
+// Times each conv layer of the VGG-Face stack and the gallery scan at several shapes with HIP
+// events, on random data, and prints ms + TFLOP/s or GB/s per kernel.
+//   kbench conv [B]            every conv layer at batch B (default 256)
+//   kbench scan                the scan at the benchmark shapes
+//   kbench all
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../face-recognition_amd/csrc/frhot_kernels.h"
+
+using namespace frhot;
+#if FR_DBG & 8
+namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
+#endif
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            fprintf(stderr, "%s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                           \
+        }                                                                                      \
+    } while (0)
+
+static uint64_t sm64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// fp16 bits of a uniform value in [-amp, amp)
+static uint16_t f2h(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+static void* dev_random_f16(size_t n, float amp, uint64_t seed) {
+    // a 1 Mi-element random block tiled over the buffer: random enough for clocks and caches
+    const size_t blk = 1 << 20;
+    std::vector<uint16_t> h(blk);
+    uint64_t s = seed;
+    for (size_t i = 0; i < blk; ++i) h[i] = f2h(((float)(sm64(s) >> 40) / 8388608.0f - 1.0f) * amp);
+    void* d;
+    CK(hipMalloc(&d, n * 2));
+    for (size_t o = 0; o < n; o += blk) {
+        const size_t c = n - o < blk ? n - o : blk;
+        CK(hipMemcpy((char*)d + o * 2, h.data(), c * 2, hipMemcpyHostToDevice));
+    }
+    return d;
+}
+
+template <class F>
+static float time_ms(F&& f, int warm, int iters, hipStream_t s) {
+    for (int i = 0; i < warm; ++i) f();
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b, s));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return ms / iters;
+}
+
+static void bench_conv(int B) {
+    static const ConvLayerDesc L[] = {
+        {224, 64, 64, 1, 1},  {112, 64, 128, 0, 1}, {112, 128, 128, 1, 1}, {56, 128, 256, 0, 1},
+        {56, 256, 256, 0, 1}, {56, 256, 256, 1, 1}, {28, 256, 512, 0, 1},  {28, 512, 512, 0, 1},
+        {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
+    };
+    static const char* names[] = {"conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
+                                  "conv4_1", "conv4_2", "conv4_3", "conv5_1/2", "conv5_3"};
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    void* dump;
+    CK(hipMalloc(&dump, 4096));
+    double tot_ms = 0, tot_fl = 0;
+    {
+        // conv1_1
+        void* x0 = dev_random_f16((size_t)B * 226 * 226 * 4, 8.0f, 1);
+        void* w = dev_random_f16(64 * 64, 0.1f, 2);
+        float* bias;
+        CK(hipMalloc((void**)&bias, 64 * 4));
+        CK(hipMemset(bias, 0, 64 * 4));
+        void* y;
+        CK(hipMalloc(&y, (size_t)B * 226 * 226 * 64 * 2));
+        const float ms = time_ms([&] { CK(launch_conv1_1(x0, w, bias, y, B, s)); }, 2, 10, s);
+        const double bytes = (double)B * 224 * 224 * 64 * 2;
+        printf("%-10s %8.3f ms  store %7.1f GB/s\n", "conv1_1", ms, bytes / ms / 1e6);
+        tot_ms += ms;
+        tot_fl += 2.0 * B * 224 * 224 * 27 * 64;
+        CK(hipFree(x0)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(y));
+    }
+    for (int i = 0; i < 11; ++i) {
+        const ConvLayerDesc& d = L[i];
+        const size_t xin = (size_t)B * (d.hw + 2) * (d.hw + 2) * d.cin;
+        const int ho = d.pool ? d.hw / 2 : d.hw;
+        const size_t yout = (size_t)B * (ho + 2 * d.opad) * (ho + 2 * d.opad) * d.cout;
+        void* x = dev_random_f16(xin, 1.0f, 10 + i);
+        void* w = dev_random_f16((size_t)d.cout * 9 * d.cin, 0.05f, 40 + i);
+        float* bias;
+        CK(hipMalloc((void**)&bias, d.cout * 4));
+        CK(hipMemset(bias, 0, d.cout * 4));
+        void* y;
+        CK(hipMalloc(&y, yout * 2));
+        CK(hipMemset(y, 0, yout * 2));
+        const float ms = time_ms([&] { CK(launch_conv3x3(d, x, w, bias, y, dump, B, s)); }, 2, 10, s);
+        const double fl = 2.0 * B * d.hw * d.hw * 9.0 * d.cin * d.cout;
+        const int reps = (i == 9) ? 2 : 1;
+        printf("%-10s %8.3f ms  %7.1f TFLOP/s   (hw %d cin %d cout %d pool %d)\n", names[i], ms, fl / ms / 1e9,
+               d.hw, d.cin, d.cout, d.pool);
+#if FR_DBG & 8
+        if (i < 3) {
+            unsigned long long st[64];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(frhot::g_stamp), sizeof st));
+            for (int wv = 0; wv < 8; ++wv)
+                printf("   wave %d: per item main %6.0f epi %6.0f barrier %6.0f cycles (%llu items)\n", wv,
+                       (double)st[wv * 4] / st[wv * 4 + 3], (double)st[wv * 4 + 1] / st[wv * 4 + 3],
+                       (double)st[wv * 4 + 2] / st[wv * 4 + 3], st[wv * 4 + 3]);
+        }
+#endif
+        tot_ms += ms * reps;
+        tot_fl += fl * reps;
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(y));
+    }
+    printf("conv stack %8.3f ms  %7.1f TFLOP/s at batch %d\n", tot_ms, tot_fl / tot_ms / 1e9, B);
+    CK(hipFree(dump));
+    CK(hipStreamDestroy(s));
+}
+
+static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream_t s) {
+    const size_t padded = ((size_t)N + 255) & ~(size_t)255;
+    void* g;
+    int32_t* gk;
+    CK(hipMalloc(&g, padded * D * 2));
+    CK(hipMalloc((void**)&gk, padded * 4));
+    CK(launch_gallery_fill(g, gk, D, 0xFACE0000ull + N, 0, N, use_keys ? 4 : 0, 0, s));
+    void* q = dev_random_f16((size_t)Bq * D, 0.05f, 7);
+    int32_t* qk = nullptr;
+    if (use_keys) {
+        CK(hipMalloc((void**)&qk, Bq * 4));
+        CK(hipMemset(qk, 0, Bq * 4));   // every query asks for key 0
+    }
+    const int kl = scan_list_len(k);
+    float* ps;
+    int64_t* pr;
+    CK(hipMalloc((void**)&ps, (size_t)scan_max_blocks() * Bq * kl * 4));
+    CK(hipMalloc((void**)&pr, (size_t)scan_max_blocks() * Bq * kl * 8));
+    int nblk = 0;
+    const float ms = time_ms(
+        [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, &nblk, s)); }, 2, 10, s);
+    const double bytes = (double)N * D * 2 + (use_keys ? (double)N * 4 : 0.0) + (double)Bq * D * 2;
+    const double fl = 2.0 * Bq * (double)N * D;
+    printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d\n",
+           N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk);
+    CK(hipFree(g)); CK(hipFree(gk)); CK(hipFree(q)); CK(hipFree(ps)); CK(hipFree(pr));
+    if (qk) CK(hipFree(qk));
+}
+
+static void bench_scan() {
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    bench_scan_one(1000000, 512, 64, 10, 0, s);
+    bench_scan_one(1000000, 512, 64, 5, 0, s);
+    bench_scan_one(10000000, 512, 64, 5, 0, s);
+    bench_scan_one(10000000, 512, 128, 5, 0, s);
+    bench_scan_one(10000000, 512, 256, 5, 0, s);
+    bench_scan_one(10000000, 512, 256, 5, 1, s);
+    bench_scan_one(1250000, 512, 2048, 5, 0, s);
+    bench_scan_one(1000000, 4096, 256, 5, 0, s);
+    CK(hipStreamDestroy(s));
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "all";
+    CK(kernels_init());
+    if (!strcmp(what, "conv") || !strcmp(what, "all")) bench_conv(argc > 2 ? atoi(argv[2]) : 256);
+    if (!strcmp(what, "scan") || !strcmp(what, "all")) bench_scan();
+    return 0;
+}
