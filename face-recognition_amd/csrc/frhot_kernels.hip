@@ -778,12 +778,14 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     constexpr int TX = 256 / WX, TY = RY / WY, NX = TX / 16, NY = TY / 16;
     constexpr int YB = RY * 128, NPY = RY / 64;
     constexpr bool RES = (NKS * YB + 2 * PATCH_B) <= 160 * 1024;
-    constexpr int WS = RES ? NKS : 4;
     constexpr int TPR = HW / 16, TPI = TPR * TPR;   // tiles per row / per image
     constexpr int IW = HW + 2;
     constexpr int NCH = NX * NY / 2;                // epilogue chunks (one 16-B store each) per wave and tile
+    // small wave tiles keep the finished tile in a second accumulator set and spread its epilogue
+    // over the next tile's MFMA phases; large ones (no registers to spare) run it at the tile's end
+    constexpr bool DEFER = NCH <= 4;
     static_assert(NX % 2 == 0 && NY % 2 == 0 && NCH <= 18, "wave tile");
-    static_assert(2 * (NPY + 1) + 4 <= 63, "vmcnt range");
+    static_assert(2 * (NPY + 1) + 6 <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const patch = smem;
     char* const wring = smem + 2 * PATCH_B;
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const int sig = (((px >> 1) & 3) << 1) | (py & 1);
         poff[t] = ((py * IW + px) * CIN) * 2 + ((l7 ^ sig) << 4);
     }
-    auto item_src = [&](long item) -> const char* {
+    auto item_src = [&](long item) __attribute__((always_inline)) -> const char* {
         const long tile = wk + (item / CPK) * G;
         const int c = (int)(item % CPK);
         const long st = tile / NT;
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const int ty = rem / TPR, tx = rem - ty * TPR;
         return (const char*)x + ((((long)b * IW + ty * 16) * IW + tx * 16) * CIN + c * 64) * 2;
     };
-    auto issue_patch = [&](const char* src, int slot, int t) {
+    auto issue_patch = [&](const char* src, int slot, int t) __attribute__((always_inline)) {
         int j = 8 * t + wave;
         j = j < NPIECE ? j : NPIECE - 1;
         glds16(src + poff[t], patch + slot * PATCH_B + j * 1024);
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const int ch = (r / TY) * TY + (cy >> 1) * 32 + g * 8 + (cy & 1) * 4 + j;
         yp[i] = (const char*)w + ((long)(n0 + ch) * K) * 2 + cb;
     }
-    auto issue_w = [&](int stage, int ks) {     // ks = chunk*9 + tap
+    auto issue_w = [&](int stage, int ks) __attribute__((always_inline)) {     // ks = chunk*9 + tap
         const int c = ks / 9, t = ks - c * 9;
         const size_t off = ((size_t)t * CIN + c * 64) * 2;
 #pragma unroll
@@ -865,8 +867,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     // acc: the tile being accumulated; accp: the finished tile before it, whose epilogue
     // (bias, ReLU, pooling, fp16, store) is spread over the MFMA blocks of the current tile so
     // that its vector work hides behind them instead of stalling every wave at the tile seam.
-    float4v acc[NY][NX], accp[NY][NX];
-    auto zero = [&]() {
+    float4v acc[NY][NX], accp[DEFER ? NY : 1][DEFER ? NX : 1];
+    auto zero = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < NY; ++a)
 #pragma unroll
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     constexpr int HO = POOL ? HW / 2 : HW, OW = HO + 2;
     half_t* pend = dump + lane * 8;     // where chunk stores of the pending tile go; dump: no tile pending
     long pend_stride_on = 0;            // 1 once a real tile is pending (0 keeps every chunk inside dump)
-    auto tile_out = [&](long tile) -> half_t* {
+    auto tile_out = [&](long tile) __attribute__((always_inline)) -> half_t* {
         const long st = tile / NT;
         const int b = (int)(st / TPI), rem = (int)(st % TPI);
         const int ty = rem / TPR, tx = rem - ty * TPR;
@@ -886,14 +888,14 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         else { oy = ty * 16 + 2 * (a0 >> 1) + dy; ox = tx * 16 + dx; }
         return y + (((long)b * OW + oy + 1) * OW + ox + 1) * COUT + n0 + wy * TY + g0 * 8;
     };
-    auto quad_max = [&](float v) -> float {
+    auto quad_max = [&](float v) __attribute__((always_inline)) -> float {
         // max over the 2x2 window = the four lanes of a quad (row-local DPP, no LDS traffic)
         int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);   // lanes ^1
         v = fmaxf(v, __builtin_bit_cast(float, t));
         t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);       // lanes ^2
         return fmaxf(v, __builtin_bit_cast(float, t));
     };
-    auto epi_chunk = [&](auto jc) {
+    auto epi_chunk = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         if constexpr (j < NCH) {
             constexpr int b2 = j / (NY / 2), u = j % (NY / 2);
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
             half8 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                float4v v = accp[2 * u + h][b2];
+                float4v v = DEFER ? accp[DEFER ? 2 * u + h : 0][DEFER ? b2 : 0] : acc[2 * u + h][b2];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     float t2 = POOL ? quad_max(v[jj]) : v[jj];
@@ -912,36 +914,97 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
 #if !(FR_DBG & 1)
             if (!POOL || (lane & 3) == 0) *(half8*)(pend + (boff + u * 32) * pend_stride_on) = o;
 #else
-            asm volatile("" ::"v"(o), "v"(pend));
+            { half_t* pp = pend; asm volatile("" ::"v"(o), "v"(pp)); }
 #endif
         }
     };
 
-    half8 fxA[NX], fyA[NY], fxB[NX], fyB[NY];
-    auto load_frags = [&](auto tapc, auto kkc, int chunk, long s, const char* pb, half8 (&fx)[NX], half8 (&fy)[NY]) {
-        constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+    // ---- ping-pong schedule ------------------------------------------------------------------
+    // Waves 0..3 (group A) and 4..7 (group B) share the SIMDs pairwise and run one phase apart,
+    // every phase ending in a workgroup barrier: while one group issues the step's LDS-DMA and
+    // reads its fragments (L), the other runs its MFMAs (M), so a SIMD's matrix pipe always has
+    // exactly one wave feeding it and the other wave's memory work hides behind that.
+    //   phase 2s  :  A: L(s)      B: M(s-1)
+    //   phase 2s+1:  A: M(s)      B: L(s)
+    const bool isA = wave < 4;
+    // a phase handles U of the step's two 32-deep K blocks: 16 MFMAs per wave either way
+    constexpr int U = (NX * NY >= 16) ? 1 : 2, NU = 2 / U;
+    half8 fx[U][NX], fy[U][NY];
+    auto phase_L = [&](auto tapc, auto uc, int chunk, long s, int slot, const char* nsrc) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value, u = decltype(uc)::value;
         constexpr int r = tap / 3, sx = tap - 3 * r;
+        // the step's LDS-DMA issues are spread over its L phases (an issue costs the wave tens of
+        // cycles, and an L phase has to fit beside the partner's 16 MFMAs)
+#if !(FR_DBG & 16) && !defined(FR_W_IN_M)
+        if (u == 0) {
+            if (!RES) {
+                if (s + 3 < S) issue_w((int)((s + 3) & 3), (int)((s + 3) % NKS));
+            }
+        }
+#endif
+#if !(FR_DBG & 2)
+        if (u == NU - 1) {
+            if (tap < 6) issue_patch(nsrc, slot ^ 1, tap);
+        }
+#endif
+        const char* const pb = patch + slot * PATCH_B;
         const char* const wb = wring + (RES ? (chunk * 9 + tap) : (int)(s & 3)) * YB;
-        const int wc = (((kk * 4 + g0) ^ l7) << 4);
 #pragma unroll
-        for (int a = 0; a < NY; ++a) fy[a] = *(const half8*)(wb + wrow + a * 16 * 128 + wc);
-        const int pc = ((kk * 64 + (g0 << 4)) ^ sgx[sx] ^ ((dy ^ (r & 1)) << 4));
+        for (int k2 = 0; k2 < U; ++k2) {
+            const int kk = u * U + k2;
+            const int wc = (((kk * 4 + g0) ^ l7) << 4);
 #pragma unroll
-        for (int b2 = 0; b2 < NX; ++b2) {
-            const int blk = (((b2 >> 1) * 2 + r) * PW + 8 * (b2 & 1) + sx) * 128;
-            fx[b2] = *(const half8*)(pb + lane_px + blk + pc);
+            for (int a = 0; a < NY; ++a) fy[k2][a] = *(const half8*)(wb + wrow + a * 16 * 128 + wc);
+            const int pc = ((kk * 64 + (g0 << 4)) ^ sgx[sx] ^ ((dy ^ (r & 1)) << 4));
+#pragma unroll
+            for (int b2 = 0; b2 < NX; ++b2) {
+                const int blk = (((b2 >> 1) * 2 + r) * PW + 8 * (b2 & 1) + sx) * 128;
+                fx[k2][b2] = *(const half8*)(pb + lane_px + blk + pc);
+            }
         }
     };
-    auto mma = [&](const half8 (&fx)[NX], const half8 (&fy)[NY]) {
-#if FR_DBG & 4
-        asm volatile("" ::"v"(fx[0]), "v"(fx[NX - 1]), "v"(fy[0]), "v"(fy[NY - 1]));
-        return;
+    auto phase_M = [&](auto tapc, auto uc, int chunk, long tile, long s) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tapc)::value, u = decltype(uc)::value;
+#if defined(FR_W_IN_M)
+        if (u == 0 && NU == 2) {
+            if (!RES) {
+                if (s + 3 < S) issue_w((int)((s + 3) & 3), (int)((s + 3) % NKS));
+            }
+        }
 #endif
+#if !(FR_DBG & 4)
 #pragma unroll
-        for (int a = 0; a < NY; ++a)
+        for (int k2 = 0; k2 < U; ++k2)
 #pragma unroll
-            for (int b2 = 0; b2 < NX; ++b2)
-                acc[a][b2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[a], fx[b2], acc[a][b2], 0, 0, 0);
+            for (int a = 0; a < NY; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < NX; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[k2][a], fx[k2][b2], acc[a][b2], 0, 0, 0);
+#endif
+        if (u != NU - 1) return;
+        if (DEFER) {
+            if (chunk == 0) {
+                epi_chunk(std::integral_constant<int, 2 * tap>{});
+                epi_chunk(std::integral_constant<int, 2 * tap + 1>{});
+            }
+            if (tap == 8 && chunk == CPK - 1) {
+#pragma unroll
+                for (int a = 0; a < NY; ++a)
+#pragma unroll
+                    for (int b2 = 0; b2 < NX; ++b2) accp[DEFER ? a : 0][DEFER ? b2 : 0] = acc[a][b2];
+                pend = tile_out(tile);
+                pend_stride_on = 1;
+                zero();
+            }
+        } else if (tap == 8 && chunk == CPK - 1) {
+            pend = tile_out(tile);
+            pend_stride_on = 1;
+            epi_chunk(std::integral_constant<int, 0>{}); epi_chunk(std::integral_constant<int, 1>{});
+            epi_chunk(std::integral_constant<int, 2>{}); epi_chunk(std::integral_constant<int, 3>{});
+            epi_chunk(std::integral_constant<int, 4>{}); epi_chunk(std::integral_constant<int, 5>{});
+            epi_chunk(std::integral_constant<int, 6>{}); epi_chunk(std::integral_constant<int, 7>{});
+            zero();
+        }
     };
 
     // ---- prologue -------------------------------------------------------------------------
@@ -954,92 +1017,68 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
             for (int ks = 0; ks < NKS; ++ks) issue_w(ks, ks);
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-                if (ks < S) issue_w(ks, ks % NKS);
+            for (int ks = 0; ks < 3; ++ks) issue_w(ks, ks % NKS);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
+    // Both groups run the SAME instruction stream, one unit after the other as L, barrier, M,
+    // barrier; group B passes one extra barrier first and group A one extra at the end, which
+    // puts B exactly one phase behind A for the whole kernel.
+    auto phase_barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (!isA) phase_barrier();
     long s = 0;            // global step
-    int wks = 3 % NKS;     // ks of the weight stage issued next (non-resident)
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, sum_main = 0, sum_epi = 0, sum_bar = 0;
-    (void)st0; (void)st1; (void)st2; (void)st3; (void)sum_main; (void)sum_epi; (void)sum_bar;
     for (long item = 0; item < n_items; ++item) {
-        FR_STAMP(st0);
         const int slot = (int)(item & 1);
         const int chunk = (int)(item % CPK);
+        const long tile = wk + (item / CPK) * G;
         // the item after the last re-fetches the last item's patch into the idle slot: every
         // step then issues the same number of loads, which the counted waits rely on
         const char* nsrc = item_src(item + 1 < n_items ? item + 1 : item);
-        const char* const pb = patch + slot * PATCH_B;
-        auto step = [&](auto tapc) {
+        auto step = [&](auto tapc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tapc)::value;
-            if (!RES) {
-                if (s + 3 < S) { issue_w((int)((s + 3) & 3), wks); wks = wks + 1 == NKS ? 0 : wks + 1; }
+            phase_L(tapc, std::integral_constant<int, 0>{}, chunk, s, slot, nsrc);
+            if (NU == 2) {
+                phase_barrier();
+                phase_M(tapc, std::integral_constant<int, 0>{}, chunk, tile, s);
+                phase_barrier();
+                phase_L(tapc, std::integral_constant<int, NU - 1>{}, chunk, s, slot, nsrc);
             }
-#if !(FR_DBG & 2)
-            if (tap < 6) issue_patch(nsrc, slot ^ 1, tap);
-#endif
-            // fragment sets A (kk = 0) and B (kk = 1): the reads of one set are in flight while
-            // the MFMAs of the other run; with resident weights the next tap's set A is fetched
-            // before this tap's second MFMA block (nothing separates the taps of an item)
-            if (!RES || tap == 0) load_frags(tapc, std::integral_constant<int, 0>{}, chunk, s, pb, fxA, fyA);
-            // (the waits are written out so that each sits BEFORE the next set's reads are issued:
-            // left to the compiler they land after them, as lgkmcnt(0), and serialise the two)
-            __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): set A has landed
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(tapc, std::integral_constant<int, 1>{}, chunk, s, pb, fxB, fyB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fxA, fyA);
-            __builtin_amdgcn_sched_barrier(0);
-            if (chunk == 0) epi_chunk(std::integral_constant<int, 2 * tap>{});
-            __builtin_amdgcn_s_waitcnt(0xC07F);     // set B has landed
-            __builtin_amdgcn_sched_barrier(0);
-            if (RES && tap < 8)
-                load_frags(std::integral_constant<int, (tap < 8 ? tap + 1 : 8)>{}, std::integral_constant<int, 0>{}, chunk,
-                           s, pb, fxA, fyA);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fxB, fyB);
-            __builtin_amdgcn_sched_barrier(0);
-            if (chunk == 0) epi_chunk(std::integral_constant<int, 2 * tap + 1>{});
-            const bool tile_end = (tap == 8) && (chunk == CPK - 1);
-            if (tap == 8) FR_STAMP(st1);
-            if (tile_end) {
-#pragma unroll
-                for (int a = 0; a < NY; ++a)
-#pragma unroll
-                    for (int b2 = 0; b2 < NX; ++b2) accp[a][b2] = acc[a][b2];
-                pend = tile_out(wk + (item / CPK) * G);
-                pend_stride_on = 1;
-                zero();
-            }
-            if (tap == 8) FR_STAMP(st2);
-            // ---- end of step: what may stay in flight ---------------------------------------
+            // End of the step's last L phase.  Before the barrier that follows, this wave's pieces
+            // of weight stage s+1 (issued in L(s-2)) and everything older (at tap 8: the next
+            // patch) must have landed: group A reads them two phases from here, group B's partner
+            // one.  What was issued after L(s-2)'s loads stays in flight: e(s-2), l(s-1), e(s-1),
+            // l(s), with l(t) = NPY weight pieces + one patch piece in taps 0..5 and e(t) = the
+            // epilogue stores of M(t).
             if (RES) {
-                // only the item's last step needs anything: the next patch and the pending tile's
-                // stores were all issued at least three steps ago
-                if (tap == 8) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+                if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                // everything issued before step s-1 must have landed (weights of step s+1 and,
-                // at tap 8, the next patch); the loads and epilogue stores of steps s-1 and s
-                // stay in flight.  Per step: NPY weight pieces, one patch piece in taps 0..5 and,
-                // in a tile's first item, the stores of epilogue chunks 2*tap and 2*tap+1.
-                constexpr int l_prev = NPY + ((tap + 8) % 9 < 6 ? 1 : 0), l_cur = NPY + (tap < 6 ? 1 : 0);
-                constexpr int e_prev = tap == 0 ? 0 : (2 * (tap - 1) < NCH) + (2 * (tap - 1) + 1 < NCH);
-                constexpr int e_cur = (2 * tap < NCH) + (2 * tap + 1 < NCH);
+                constexpr int l1 = NPY + ((tap + 8) % 9 < 6 ? 1 : 0), l0 = NPY + (tap < 6 ? 1 : 0);
                 if (s + 4 >= S) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (chunk == 0) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l_prev + l_cur + e_prev + e_cur) : "memory");
+                } else if (DEFER) {
+                    constexpr int e2 = tap < 2 ? 0 : (2 * (tap - 2) < NCH) + (2 * (tap - 2) + 1 < NCH);
+                    constexpr int e1 = tap < 1 ? 0 : (2 * (tap - 1) < NCH) + (2 * (tap - 1) + 1 < NCH);
+                    if (chunk == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l1 + l0 + e2 + e1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l1 + l0) : "memory");
                 } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l_prev + l_cur) : "memory");
+                    // stores: all NCH in M(tap 8) of a tile's last item
+                    if (tap <= 1 && chunk == 0 && item > 0)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l1 + l0 + NCH) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l1 + l0) : "memory");
                 }
-                __builtin_amdgcn_s_barrier();
             }
+            phase_barrier();
+            phase_M(tapc, std::integral_constant<int, NU - 1>{}, chunk, tile, s);
+            phase_barrier();
             ++s;
         };
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
@@ -1047,23 +1086,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
         step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
         step(std::integral_constant<int, 8>{});
-        FR_STAMP(st3);
-#if FR_DBG & 8
-        sum_main += st1 - st0; sum_epi += st2 - st1; sum_bar += st3 - st2;
-#endif
     }
-    // epilogue of the last tile
-    epi_chunk(std::integral_constant<int, 0>{}); epi_chunk(std::integral_constant<int, 1>{});
-    epi_chunk(std::integral_constant<int, 2>{}); epi_chunk(std::integral_constant<int, 3>{});
-    epi_chunk(std::integral_constant<int, 4>{}); epi_chunk(std::integral_constant<int, 5>{});
-    epi_chunk(std::integral_constant<int, 6>{}); epi_chunk(std::integral_constant<int, 7>{});
-    static_assert(NCH <= 8, "flush list");
-#if FR_DBG & 8
-    if (blockIdx.x == 0 && lane == 0) {
-        g_stamp[wave * 4 + 0] = sum_main; g_stamp[wave * 4 + 1] = sum_epi; g_stamp[wave * 4 + 2] = sum_bar;
-        g_stamp[wave * 4 + 3] = (unsigned long long)n_items;
+    if (isA) phase_barrier();
+    static_assert(NCH <= 8, "chunk lists");
+    if (DEFER) {    // epilogue of the last tile
+        epi_chunk(std::integral_constant<int, 0>{}); epi_chunk(std::integral_constant<int, 1>{});
+        epi_chunk(std::integral_constant<int, 2>{}); epi_chunk(std::integral_constant<int, 3>{});
     }
-#endif
 }
 
 // Gallery scan, 8 waves: gallery tile 256 rows (MFMA A operand), query tile RY in

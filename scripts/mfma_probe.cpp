@@ -65,6 +65,27 @@ __global__ __launch_bounds__(512) void probe(const _Float16* __restrict__ src, f
             load(it, fa0, fb0);
             mma(fa0, fb0);
         }
+    } else if (MODE == 4 || MODE == 5 || MODE == 6) {
+        // barrier-paced phases: reads | barrier | MFMAs | barrier; MODE 4: waves 4..7 run one
+        // barrier behind (ping-pong); MODE 5: all waves in step; MODE 6: as 4 with s_setprio
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (MODE != 5 && late) bar();
+        for (int it = 0; it < iters; ++it) {
+            load(it, fa0, fb0);
+            bar();
+            if (MODE == 6) __builtin_amdgcn_s_setprio(1);
+            mma(fa0, fb0);
+            if (MODE == 6) __builtin_amdgcn_s_setprio(0);
+            bar();
+        }
+        if (MODE != 5 && !late) bar();
     } else {
         if (MODE == 2 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_sleep(NA * NB / 8);
         load(0, fa0, fb0);
@@ -129,5 +150,7 @@ int main() {
     run<4, 4, 0>(src, out, 8); run<4, 4, 1>(src, out, 8); run<4, 4, 2>(src, out, 8); run<4, 4, 3>(src, out, 8);
     run<4, 8, 0>(src, out, 8); run<4, 8, 1>(src, out, 8); run<4, 8, 2>(src, out, 8); run<4, 8, 3>(src, out, 8);
     run<4, 4, 0>(src, out, 4); run<4, 4, 1>(src, out, 4); run<4, 8, 1>(src, out, 4);
+    run<4, 4, 4>(src, out, 8); run<4, 4, 5>(src, out, 8); run<4, 4, 6>(src, out, 8);
+    run<4, 8, 4>(src, out, 8); run<4, 8, 5>(src, out, 8); run<2, 4, 4>(src, out, 8);
     return 0;
 }
