@@ -234,3 +234,49 @@ def test_errors_are_reported(gpu_ctx):
     s, r = gal.search(np.ones((2, 64), np.float32), None, 5)         # empty gallery
     assert (r == -1).all() and np.isneginf(s).all()
     gal.close()
+
+
+def test_row_sharded_search_dev_merge(gpu_ctx):
+    """The N > 1 data path on one GPU: two row shards searched with frhot_search_dev (row_base
+    added), lists stacked as an all-gather would, merged with frhot_merge_topk_dev; the result
+    must equal one search over the whole gallery, including a tie that straddles the shards."""
+    import torch
+    from frhot import synth
+    from frhot.dist import ShardedSearch, shard_rows
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    n, d, bq, k, P = 6001, 512, 37, 5, 2
+    g = synth.unit_gallery(seed=9, n=n, d=d)
+    g[n - 1] = g[0]
+    rng = np.random.default_rng(10)
+    targets = rng.integers(0, n, size=bq)
+    q = synth.planted_queries(rng, g[targets], 0.8)
+    q[0] = g[0]
+    dev = torch.device("cuda", 0)
+    q16 = torch.from_numpy(osr.unit_rows(q).astype(np.float16)).to(dev)
+    shards, lists_s, lists_r = [], [], []
+    for r in range(P):
+        base, rows = shard_rows(n, P, r)
+        gal = Gallery(gpu_ctx, d, rows)
+        gal.upsert(g[base:base + rows], 0, np.arange(rows))
+        s_out = torch.empty((bq, k), dtype=torch.float32, device=dev)
+        r_out = torch.empty((bq, k), dtype=torch.int64, device=dev)
+        gal.search_dev(q16.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), base)
+        shards.append(gal)
+        lists_s.append(s_out)
+        lists_r.append(r_out)
+    gpu_ctx.sync()                      # the library enqueues on its own stream
+    s_all = torch.stack(lists_s).contiguous()
+    r_all = torch.stack(lists_r).contiguous()
+    torch.cuda.synchronize()
+    out_s = torch.empty((bq, k), dtype=torch.float32, device=dev)
+    out_r = torch.empty((bq, k), dtype=torch.int64, device=dev)
+    gpu_ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, bq, k, out_s.data_ptr(), out_r.data_ptr())
+    gpu_ctx.sync()
+    got_s, got_r = out_s.cpu().numpy(), out_r.cpu().numpy()
+    ref_s, ref_r = osr.cosine_topk(q, g, k, gallery_dtype=np.float16)
+    full = osr.unit_rows(q).astype(np.float16).astype(np.float32) @ osr.unit_rows(g).astype(np.float16).astype(np.float32).T
+    _check_topk(got_s, got_r, ref_s, ref_r, full, tol=2e-5)
+    assert list(got_r[0, :2]) == [0, n - 1]
+    for gal in shards:
+        gal.close()
