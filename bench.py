@@ -209,7 +209,7 @@ def main():
                                         f"{args.gallery_rows}x{D} fp16 gallery row-sharded over {P} GPU(s)"),
                            "batch_per_gpu": B, "gallery_rows": args.gallery_rows, "dim": D, "k": K,
                            "parallelism": f"dp{P}+rowshard{P}"},
-                "roofline": {"kernel": "scan_topk8_kernel", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
+                "roofline": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None,
                              "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": stages["scan"],
                              "mfma_tflops": scan_tf, "mfma_frac": scan_tf / MFMA_PEAK_TFLOPS,

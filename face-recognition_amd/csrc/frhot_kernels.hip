@@ -660,22 +660,27 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     }
 
     long itile = wk;                 // issue side: tile and tap position of the next streamed step
-    int ir = 0, is = 0, icc = 0, yks = 0;
+    int ir = 0, is = 0, icc = 0;
     set_pixels(itile);
+    // K order: the nine taps of one 64-channel chunk run back to back (channel chunk outermost),
+    // so the shifted re-reads of a pixel row's chunk come within nine steps of each other and
+    // the XCD's L2 still holds them (with the taps outermost the re-reads were CIN/64 steps apart
+    // and a round's working set exceeded the 4 MiB L2).
     auto next_x = [&](int slot) {
         const size_t off = ((size_t)(ir * PW + is) * CIN + icc * 64) * 2;
         Core::issue_x(xs + slot * Core::XB, wave, xp, off);
-        if (++icc == CPK) {
-            icc = 0;
-            if (++is == 3) {
-                is = 0;
-                if (++ir == 3) { ir = 0; itile += G; set_pixels(itile < ntiles ? itile : ntiles - 1); }
+        if (++is == 3) {
+            is = 0;
+            if (++ir == 3) {
+                ir = 0;
+                if (++icc == CPK) { icc = 0; itile += G; set_pixels(itile < ntiles ? itile : ntiles - 1); }
             }
         }
     };
+    int ytap = 0, ycc = 0;
     auto next_y = [&](int slot) {
-        Core::issue_y(ys + slot * Core::YB, wave, yp, (size_t)yks * 128);
-        if (++yks == NK) yks = 0;
+        Core::issue_y(ys + slot * Core::YB, wave, yp, ((size_t)ytap * CIN + ycc * 64) * 2);
+        if (++ytap == 9) { ytap = 0; if (++ycc == CPK) ycc = 0; }
     };
 
     Core core;
@@ -1095,27 +1100,44 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     }
 }
 
-// Gallery scan, 8 waves: gallery tile 256 rows (MFMA A operand), query tile RY in
-// {64,128,256} (B operand, one query per lane & 15).  The 1-D grid holds nb gallery
-// walkers per query tile; walker gb visits gallery tiles gb, gb+nb, ...  Blocks that
-// differ only in their query tile are adjacent on one XCD so that the gallery stream of
-// one is an L2 hit for the others.  The gallery allocation is padded to whole tiles, so
-// loads never leave it; rows >= nrows are masked in the last tile.
-template <int K, int RY, int WX, int WY, bool USE_KEYS>
-__global__ __launch_bounds__(512) void scan_topk8_kernel(const half_t* __restrict__ gal,
-                                                         const int32_t* __restrict__ gkeys, long nrows, int D,
-                                                         const half_t* __restrict__ q,
-                                                         const int32_t* __restrict__ qkeys, int Bq, int nb,
-                                                         float* __restrict__ part_s, long long* __restrict__ part_r) {
-    using Core = GemmCore8<256, RY, WX, WY, true>;
-    constexpr int NY = Core::NY, NX = Core::NX;
+// Gallery scan.  Tile = 256 gallery rows (MFMA A operand, streamed from HBM through an LDS-DMA
+// ring) by RY in {64,128,256} queries (B operand, one query per lane & 15; its 64-deep slices
+// come from L2 through a second ring).  The 1-D grid holds nb gallery walkers per query tile;
+// walker gb visits gallery tiles gb, gb+nb, ...  Blocks that differ only in their query tile are
+// adjacent on one XCD so that the gallery stream of one is an L2 hit for the others.  The
+// gallery allocation is padded to whole tiles, so loads never leave it; rows >= nrows are
+// masked in the last tile.  Ring depths are chosen per query tile so that the LDS is used up:
+// the gallery stream runs XS-1 steps ahead (HBM latency), the query slices YS-1 steps (L2).
+// PP selects the ping-pong schedule (waves 0..3 and 4..7 one barrier-delimited phase apart, one
+// group reading fragments and issuing LDS-DMA while the other runs MFMAs); measured on MI355X
+// it is 5-10 % slower than the lock-step schedule for this kernel, whose steps are paced by the
+// arrival of HBM data rather than by instruction issue, so the library instantiates PP = false.
+// Top-k: every lane keeps a sorted list per query column; before a tile's 4*NX new scores are
+// examined, the four lanes that share a query exchange their k-th best: a score below the best
+// of those can never reach the final list.
+template <int K, int RY, int WX, int WY, bool USE_KEYS, bool PP>
+__global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict__ gal,
+                                                           const int32_t* __restrict__ gkeys, long nrows, int D,
+                                                           const half_t* __restrict__ q,
+                                                           const int32_t* __restrict__ qkeys, int Bq, int nb,
+                                                           float* __restrict__ part_s, long long* __restrict__ part_r) {
+    static_assert(WX * WY == 8 && RY % 64 == 0, "shape");
+    constexpr int TX = 256 / WX, TY = RY / WY, NX = TX / 16, NY = TY / 16;
+    constexpr int XB = 256 * 128, YB = RY * 128;
+    constexpr int XS = RY <= 64 ? 4 : 3, YS = RY <= 128 ? 3 : 2;
+    constexpr int DX = XS - 1, DY = YS - 1;
+    constexpr int NPX = 4, NPY = RY / 64;
+    constexpr int U = (NX * NY >= 16) ? 1 : 2, NU = 2 / U;
+    // loads that may stay in flight at the end of a step's last L phase (see the wait below)
+    constexpr int INFLIGHT = (DX == 3 && DY == 2) ? 2 * NPX + NPY : (DX == 2 && DY == 2) ? NPX + NPY : NPX;
+    static_assert((DX == 3 && DY == 2) || (DX == 2 && DY == 2) || (DX == 2 && DY == 1), "ring depths");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs = smem;
-    char* const ys = smem + Core::XS * Core::XB;
+    char* const ys = smem + XS * XB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = wave / WY, wy = wave % WY;
-    const int l15 = lane & 15, g0 = lane >> 4;
+    const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
     const int qtiles = gridDim.x / nb;
     const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
     const int qt = seq % qtiles, gb = (seq / qtiles) * 8 + xcd;
@@ -1124,58 +1146,128 @@ __global__ __launch_bounds__(512) void scan_topk8_kernel(const half_t* __restric
     const long ntiles = (nrows + 255) / 256;
     const long my_tiles = gb < ntiles ? (ntiles - gb + nb - 1) / nb : 0;
     const long S = my_tiles * nk;
-    const int cb = Core::stage_chunk_bytes(lane);
+    const int cb = ((l7 ^ (lane >> 3)) << 4);
 
-    const char* xp[Core::NPX];
-    const char* yp[Core::NPY];
+    const char* xp[NPX];
+    const char* yp[NPY];
 #pragma unroll
-    for (int i = 0; i < Core::NPX; ++i)
-        xp[i] = (const char*)gal + (size_t)Core::stage_row(wave, lane, i) * D * 2 + cb;
+    for (int i = 0; i < NPX; ++i)
+        xp[i] = (const char*)gal + (size_t)(8 * (wave + 8 * i) + (lane >> 3)) * D * 2 + cb;
 #pragma unroll
-    for (int i = 0; i < Core::NPY; ++i) {
-        int qq = q0 + Core::stage_row(wave, lane, i);
+    for (int i = 0; i < NPY; ++i) {
+        int qq = q0 + 8 * (wave + 8 * i) + (lane >> 3);
         qq = qq < Bq ? qq : Bq - 1;
         yp[i] = (const char*)q + (size_t)qq * D * 2 + cb;
     }
     int mykey[NY];
 #pragma unroll
     for (int y = 0; y < NY; ++y) {
-        const int qq = q0 + wy * Core::TY + y * 16 + l15;
+        const int qq = q0 + wy * TY + y * 16 + l15;
         mykey[y] = (USE_KEYS && qkeys && qq < Bq) ? qkeys[qq] : -2;
     }
     TopK<K> top[NY];
 #pragma unroll
     for (int y = 0; y < NY; ++y) top[y].init();
 
-    Core core;
-    core.zero();
+    float4v acc[NY][NX];
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+        for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
+
     if (S > 0) {
-        long itile = gb; int iks = 0;   // next streamed step to issue
-        int yks = 0;                    // next resident step to issue
-        auto next_x = [&](int slot) {
+        long itile = gb; int iks = 0;   // next gallery step to issue
+        int yks = 0;                    // next query slice to issue
+        auto issue_x = [&](int slot) __attribute__((always_inline)) {
             const size_t off = ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
-            Core::issue_x(xs + slot * Core::XB, wave, xp, off);
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) glds16(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
             if (++iks == nk) { iks = 0; itile += nb; }
         };
-        auto next_y = [&](int slot) {
-            Core::issue_y(ys + slot * Core::YB, wave, yp, (size_t)yks * 128);
+        auto issue_y = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NPY; ++i) glds16(yp[i] + (size_t)yks * 128, ys + slot * YB + (wave + 8 * i) * 1024);
             if (++yks == nk) yks = 0;
         };
-        next_y(0);
-        next_x(0);
-        if (S > 1) { next_x(1); Core::wait_keep_newest(); } else { Core::wait_all(); }
+        auto phase_barrier = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // prologue: the first DY query slices and DX gallery steps; everything lands before phase 0
+#pragma unroll
+        for (int i = 0; i < DY; ++i)
+            if (i < S) issue_y(i);
+#pragma unroll
+        for (int i = 0; i < DX; ++i)
+            if (i < S) issue_x(i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+
+        const bool isA = wave < 4;
+        if (PP && !isA) phase_barrier();      // group B runs one phase behind group A from here on
+        half8 fx[U][NX], fy[U][NY];
         int xslot = 0, yslot = 0, ks = 0;
         long tile = gb;
         for (long s = 0; s < S; ++s) {
-            if (s + 1 < S) next_y(yslot ^ 1);
-            if (s + 2 < S) next_x(xslot == 0 ? 2 : xslot - 1);   // (xslot + 2) % 3
-            core.compute(xs + xslot * Core::XB, ys + yslot * Core::YB, lane, wx, wy);
+            const char* const xbuf = xs + xslot * XB;
+            const char* const ybuf = ys + yslot * YB;
+            auto phase_L = [&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                if (u == 0) {
+                    if (s + DY < S) issue_y(yslot == 0 ? YS - 1 : yslot - 1);
+                }
+                if (u == NU - 1) {
+                    if (s + DX < S) issue_x(xslot == 0 ? XS - 1 : xslot - 1);
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < U; ++k2) {
+                    const int coff = ((((u * U + k2) * 4 + g0) ^ l7) << 4);
+#pragma unroll
+                    for (int y = 0; y < NY; ++y)
+                        fy[k2][y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
+#pragma unroll
+                    for (int x = 0; x < NX; ++x)
+                        fx[k2][x] = *(const half8*)(xbuf + (wx * TX + x * 16 + l15) * 128 + coff);
+                }
+            };
+            auto phase_M = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int k2 = 0; k2 < U; ++k2)
+#pragma unroll
+                    for (int y = 0; y < NY; ++y)
+#pragma unroll
+                        for (int x = 0; x < NX; ++x)
+                            acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[k2][x], fy[k2][y], acc[y][x], 0, 0, 0);
+            };
+            phase_L(std::integral_constant<int, 0>{});
+            if (NU == 2) {
+                if (PP) phase_barrier();
+                phase_M();
+                if (PP) phase_barrier();
+                phase_L(std::integral_constant<int, NU - 1>{});
+            }
+            // Gallery step s+1 and query slice s+1 must have landed before the next step reads them
+            // (with the ping-pong schedule group A does so two phases on, hence the wait sits before
+            // the barrier that ends this L phase).  In issue order the later of the two is followed
+            // only by the loads counted in INFLIGHT, which may stay outstanding; near the end of the
+            // block's work fewer loads are issued, so everything is waited for.
+            auto step_wait = [&]() __attribute__((always_inline)) {
+                if (s + DX < S && s + DY < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            };
+            if (PP) { step_wait(); phase_barrier(); }
+            phase_M();
             if (ks == nk - 1) {
-                const long rbase = tile * 256 + wx * Core::TX + g0 * 4;
+                const long rbase = tile * 256 + wx * TX + g0 * 4;
                 const bool partial = (tile + 1) * 256 > nrows;
 #pragma unroll
                 for (int y = 0; y < NY; ++y) {
+                    float thr = top[y].s[K - 1];
+                    thr = fmaxf(thr, __shfl_xor(thr, 16));
+                    thr = fmaxf(thr, __shfl_xor(thr, 32));
                     float v[NX][4];
 #pragma unroll
                     for (int x = 0; x < NX; ++x) {
@@ -1190,31 +1282,61 @@ __global__ __launch_bounds__(512) void scan_topk8_kernel(const half_t* __restric
                             bool ok = true;
                             if (USE_KEYS) ok = (mykey[y] == -2) ? kk[j] >= 0 : kk[j] == mykey[y];
                             if (partial) ok = ok && (r0 + j < nrows);
-                            v[x][j] = ok ? core.acc[y][x][j] : -INFINITY;
+                            v[x][j] = ok ? acc[y][x][j] : -INFINITY;
                         }
                     }
                     float m = -INFINITY;
 #pragma unroll
                     for (int x = 0; x < NX; ++x) m = fmaxf(fmaxf(m, fmaxf(v[x][0], v[x][1])), fmaxf(v[x][2], v[x][3]));
-                    if (m > top[y].s[K - 1]) {
+                    // Slow path, taken while any lane still holds a score that belongs in its list:
+                    // each lane inserts its best remaining score (equal scores: lowest row first, the
+                    // order the list expects), strikes it out and looks for the next.  The cost follows
+                    // the number of real candidates per lane, not the tile's 4*NX scores.
+                    if constexpr (K < 10) {
+                        // short lists: straight-line predicated insertion of every qualifying score
+                        if (m >= thr && m > top[y].s[K - 1]) {
+#pragma unroll
+                            for (int x = 0; x < NX; ++x)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (v[x][j] >= thr && v[x][j] > top[y].s[K - 1])
+                                        top[y].template push<false>(v[x][j], (int)(rbase + x * 16 + j));
+                        }
+                    } else
+                    while (__any(m >= thr && m > top[y].s[K - 1])) {
+                        const bool want = m >= thr && m > top[y].s[K - 1];
+                        int hit = -1;
+#pragma unroll
+                        for (int x = NX - 1; x >= 0; --x)
+#pragma unroll
+                            for (int j = 3; j >= 0; --j)
+                                if (v[x][j] == m) hit = x * 16 + j;      // lowest matching (x, j) wins
+                        if (want) top[y].template push<false>(m, (int)rbase + hit);
+                        float m2 = -INFINITY;
 #pragma unroll
                         for (int x = 0; x < NX; ++x)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (v[x][j] > top[y].s[K - 1])
-                                    top[y].template push<false>(v[x][j], (int)(rbase + x * 16 + j));
+                            for (int j = 0; j < 4; ++j) {
+                                if (x * 16 + j == hit) v[x][j] = -INFINITY;
+                                m2 = fmaxf(m2, v[x][j]);
+                            }
+                        m = want ? m2 : -INFINITY;     // a lane with nothing to insert is done with this tile
                     }
                 }
-                core.zero();
+#pragma unroll
+                for (int y = 0; y < NY; ++y)
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
                 ks = 0; tile += nb;
             } else {
                 ++ks;
             }
-            if (s + 2 < S) Core::wait_keep_newest(); else Core::wait_all();
-            __builtin_amdgcn_s_barrier();
-            xslot = xslot == 2 ? 0 : xslot + 1;
-            yslot ^= 1;
+            if (!PP) step_wait();
+            phase_barrier();
+            xslot = xslot == XS - 1 ? 0 : xslot + 1;
+            yslot = yslot == YS - 1 ? 0 : yslot + 1;
         }
+        if (PP && isA) phase_barrier();
     }
 
     // merge the WX*4 lists of each query through LDS, one thread per query
@@ -1224,7 +1346,7 @@ __global__ __launch_bounds__(512) void scan_topk8_kernel(const half_t* __restric
     int* lr = (int*)(smem + RY * NL * K * 4);
 #pragma unroll
     for (int y = 0; y < NY; ++y) {
-        const int ql = wy * Core::TY + y * 16 + l15, slot = wx * 4 + g0;
+        const int ql = wy * TY + y * 16 + l15, slot = wx * 4 + g0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             ls[(ql * NL + slot) * K + i] = top[y].s[i];
@@ -1487,11 +1609,12 @@ static int scan_query_tile(int Bq, int kl) {
 template <int K, int RY, int WX, int WY, bool USE_KEYS>
 static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
                             int Bq, int nb, float* part_s, int64_t* part_r, hipStream_t s, bool attr_only) {
-    using Core = GemmCore8<256, RY, WX, WY, true>;
+    constexpr int xs = RY <= 64 ? 4 : 3, ys = RY <= 128 ? 3 : 2;
+    constexpr int ring = xs * 256 * 128 + ys * RY * 128;
     constexpr int merge = RY * WX * 4 * K * 8;
-    constexpr int lds = Core::LDS > merge ? Core::LDS : merge;
+    constexpr int lds = ring > merge ? ring : merge;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_topk8_kernel<K, RY, WX, WY, USE_KEYS>;
+    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS, false>;
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,

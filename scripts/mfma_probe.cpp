@@ -134,6 +134,105 @@ static void run(const _Float16* src, float* out, int waves) {
            fl / ms / 1e9, (double)(NA + NB) / (NA * NB));
 }
 
+
+// Ping-pong phases with NDMA LDS-DMA pieces (1 KiB each, L2-resident source) per wave and
+// iteration, issued either in the load phase (WHERE 0), in the MFMA phase before the MFMAs
+// (WHERE 1), or spread between the MFMAs (WHERE 2).
+template <int NA, int NB, int NDMA, int WHERE, int SRC>
+__global__ __launch_bounds__(512) void probe_dma(const _Float16* __restrict__ src, float* __restrict__ out, int iters,
+                                                  const char* __restrict__ big, size_t big_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 4096; i += 512) ((half8*)smem)[i] = ((const half8*)src)[i + blockIdx.x % 4 * 4096];
+    __syncthreads();
+    const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+    const char* base = smem + (wave * 16 + l15) * 128;
+    int off[2];
+    off[0] = ((g0 ^ l7) << 4);
+    off[1] = (((4 + g0) ^ l7) << 4);
+    float4v acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+    half8 fa[NA], fb[NB];
+    const char* gsrc = (const char*)src + (size_t)(blockIdx.x % 64) * 1024 + lane * 16;
+    char* dst = smem + 65536 + wave * 4096;     // DMA target region, not read by the MFMA operands
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // SRC 1: every block streams its own 8*NDMA KiB per iteration out of a buffer far larger than the caches
+    const size_t per_iter = (size_t)NDMA * 8 * 1024;
+    const char* bsrc = big + ((size_t)blockIdx.x * 4096 * per_iter) % big_bytes + wave * NDMA * 1024 + lane * 16;
+    auto dma = [&](int it, int i) {
+        const char* g = SRC == 0 ? gsrc + ((it + i) & 15) * 65536
+                                 : bsrc + (((size_t)it * per_iter) % (big_bytes / 2)) + i * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + (i & 3) * 1024), 16, 0, 0);
+    };
+    const bool late = wave >= 4;
+    if (late) bar();
+    for (int it = 0; it < iters; ++it) {
+        if (WHERE == 0) {
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) dma(it, i);
+        }
+        const char* p = base + ((it & 3) * 8192) + off[it & 1];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) fa[a] = *(const half8*)(p + a * 2048);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fb[b] = *(const half8*)(p + 32768 + b * 2048);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        bar();
+        if (WHERE == 1) {
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) dma(it, i);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            if (WHERE == 2 && a < NDMA) { __builtin_amdgcn_sched_barrier(0); dma(it, a); __builtin_amdgcn_sched_barrier(0); }
+        }
+        bar();
+    }
+    if (!late) bar();
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int NA, int NB, int NDMA, int WHERE, int SRC>
+static void run_dma(const _Float16* src, float* out, const char* big, size_t big_bytes) {
+    const int iters = 4096;
+    auto k = probe_dma<NA, NB, NDMA, WHERE, SRC>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(a));
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(256), dim3(512), 65536 + 32768, 0, src, out, iters, big, big_bytes);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= 5;
+    const double fl = 256.0 * 8 * iters * NA * NB * 16.0 * 16 * 32 * 2;
+    printf("PP NA=%d NB=%d dma/wave/iter=%d where=%d src=%d: %7.3f ms  %7.1f TFLOP/s  DMA %.0f GB/s\n", NA, NB, NDMA,
+           WHERE, SRC, ms, fl / ms / 1e9, 256.0 * 8 * iters * NDMA * 1024 / ms / 1e6);
+}
+
 int main() {
     std::vector<_Float16> h(1 << 16);
     unsigned s = 12345;
@@ -143,9 +242,20 @@ int main() {
     }
     _Float16* src;
     float* out;
-    CK(hipMalloc((void**)&src, h.size() * 2));
+    CK(hipMalloc((void**)&src, (1 << 21)));
+    CK(hipMemset(src, 0, 1 << 21));
     CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc((void**)&out, 256 * 512 * 4));
+    size_t big_bytes = (size_t)8 << 30;
+    char* big;
+    CK(hipMalloc((void**)&big, big_bytes));
+    CK(hipMemset(big, 1, big_bytes));
+    run_dma<4, 8, 0, 0, 0>(src, out, big, big_bytes);
+    run_dma<4, 8, 4, 0, 0>(src, out, big, big_bytes); run_dma<4, 8, 8, 0, 0>(src, out, big, big_bytes);
+    run_dma<4, 8, 2, 0, 1>(src, out, big, big_bytes); run_dma<4, 8, 4, 0, 1>(src, out, big, big_bytes);
+    run_dma<4, 8, 8, 0, 1>(src, out, big, big_bytes);
+    run_dma<4, 4, 4, 0, 1>(src, out, big, big_bytes); run_dma<2, 4, 4, 0, 1>(src, out, big, big_bytes);
+    return 0;
     run<2, 4, 0>(src, out, 8); run<2, 4, 1>(src, out, 8); run<2, 4, 2>(src, out, 8); run<2, 4, 3>(src, out, 8);
     run<4, 4, 0>(src, out, 8); run<4, 4, 1>(src, out, 8); run<4, 4, 2>(src, out, 8); run<4, 4, 3>(src, out, 8);
     run<4, 8, 0>(src, out, 8); run<4, 8, 1>(src, out, 8); run<4, 8, 2>(src, out, 8); run<4, 8, 3>(src, out, 8);
