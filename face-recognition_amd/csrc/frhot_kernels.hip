@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const half_t* __restrict__
         __builtin_amdgcn_wave_barrier();
         // 16 output pixels are 2 KiB contiguous in the NHWC row: lane -> 16 B at lane*16 (+1 KiB)
         char* dst = (char*)(y + (((long)b * P + py + 1) * P + px0 + 1) * 64) + lane * 16;
-        *(half8*)dst = r0;
-        *(half8*)(dst + 1024) = r1;
+        // 1.6 GB per 256 faces, read back only by the next layer: streamed past the caches
+        // (non-temporal), which writes at 5.2 TB/s instead of 3.4 TB/s
+        __builtin_nontemporal_store(r0, (half8*)dst);
+        __builtin_nontemporal_store(r1, (half8*)(dst + 1024));
     }
 }
 
@@ -917,7 +919,11 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
                 }
             }
 #if !(FR_DBG & 1)
+#ifdef FR_NT_STORE2
+            if (!POOL || (lane & 3) == 0) __builtin_nontemporal_store(o, (half8*)(pend + (boff + u * 32) * pend_stride_on));
+#else
             if (!POOL || (lane & 3) == 0) *(half8*)(pend + (boff + u * 32) * pend_stride_on) = o;
+#endif
 #else
             { half_t* pp = pend; asm volatile("" ::"v"(o), "v"(pp)); }
 #endif
