@@ -50,6 +50,12 @@ FR_DEV void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same with the non-temporal cache policy: for bytes that exactly one CU reads exactly once.
+FR_DEV void glds16_nt(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 FR_DEV uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1187,7 +1193,12 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         auto issue_x = [&](int slot) __attribute__((always_inline)) {
             const size_t off = ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
 #pragma unroll
-            for (int i = 0; i < NPX; ++i) glds16(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
+            // with one query tile every gallery byte is read by one CU, once: stream it non-temporally
+            // (+3..6 % on the HBM-bound shapes); with several, the other tiles' blocks want it in L2
+            for (int i = 0; i < NPX; ++i) {
+                if (qtiles == 1) glds16_nt(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
+                else glds16(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
+            }
             if (++iks == nk) { iks = 0; itile += nb; }
         };
         auto issue_y = [&](int slot) __attribute__((always_inline)) {
