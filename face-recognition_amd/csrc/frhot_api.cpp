@@ -624,6 +624,41 @@ int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f
     return FRHOT_OK;
 }
 
+int frhot_gallery_write_f16(frhot_gallery* g, const void* rows_f16, const int32_t* keys, const int64_t* rows, int n) {
+    if (!g || !rows_f16 || !keys || !rows) return fail(FRHOT_EINVAL, "null argument");
+    if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
+    int64_t hi = -1;
+    bool contiguous = true, inside = true;
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= g->capacity) return fail(FRHOT_ECAPACITY, "row %lld outside capacity %lld", (long long)rows[i], (long long)g->capacity);
+        if (keys[i] < FRHOT_KEY_DEAD) return fail(FRHOT_EINVAL, "key %d is not a row key", keys[i]);
+        if (rows[i] > hi) hi = rows[i];
+        if (rows[i] != rows[0] + i) contiguous = false;
+        if (rows[i] >= g->nrows) inside = false;
+    }
+    bool any_dead = false;
+    for (int i = 0; i < n; ++i) any_dead = any_dead || keys[i] == FRHOT_KEY_DEAD;
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    void* din = nullptr; int32_t* dk = nullptr; int64_t* dr = nullptr;
+    hipError_t e = hipMalloc(&din, (size_t)n * g->D * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&dk, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(din, rows_f16, (size_t)n * g->D * 2, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dk, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_scatter(din, dk, dr, n, g->D, g->rows, g->keys, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (din) (void)hipFree(din);
+    if (dk) (void)hipFree(dk);
+    if (dr) (void)hipFree(dr);
+    if (e != hipSuccess) return fail(FRHOT_EHIP, "gallery write failed: %s", hipGetErrorString(e));
+    if (any_dead || !(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
+    if (hi + 1 > g->nrows) g->nrows = hi + 1;
+    return FRHOT_OK;
+}
+
 int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev, int Bq, int k,
                      void* scores_dev, void* rows_dev, int64_t row_base) {
     if (!g) return fail(FRHOT_EINVAL, "gallery is null");

@@ -52,6 +52,8 @@ hipError_t launch_gallery_fill(void* g_f16, int32_t* g_keys, int D, uint64_t see
                                int64_t n, int nkeys, int dup_every, hipStream_t s);
 hipError_t launch_gallery_gather(const void* g_f16, const int32_t* g_keys, const int64_t* rows, int n,
                                  int D, void* out_f16, int32_t* out_keys, hipStream_t s);
+hipError_t launch_gallery_scatter(const void* in_f16, const int32_t* in_keys, const int64_t* rows, int n,
+                                  int D, void* g_f16, int32_t* g_keys, hipStream_t s);
 hipError_t launch_f32_to_unit_f16(const float* q, void* q_f16, int Bq, int D, hipStream_t s);
 
 // Scan: per-block partial top-k lists into part_s/part_r ([nblk][Bq][k]); returns nblk via *nblk_out.

@@ -488,6 +488,18 @@ __global__ __launch_bounds__(256) void gallery_gather_kernel(const half_t* __res
     if (lane == 0 && out_keys) out_keys[i] = gk[r];
 }
 
+// Inverse of the gather: rows of `in` ([n,D] fp16, already unit) and their keys go to rows[i].
+__global__ __launch_bounds__(256) void gallery_scatter_kernel(const half_t* __restrict__ in,
+                                                              const int32_t* __restrict__ in_keys,
+                                                              const int64_t* __restrict__ rows, int n, int D,
+                                                              half_t* __restrict__ g, int32_t* __restrict__ gk) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int64_t r = rows[i];
+    for (int c = lane * 8; c < D; c += 512) *(half8*)(g + (size_t)r * D + c) = *(const half8*)(in + (size_t)i * D + c);
+    if (lane == 0) gk[r] = in_keys[i];
+}
+
 __global__ __launch_bounds__(256) void f32_to_unit_f16_kernel(const float* __restrict__ q, half_t* __restrict__ o,
                                                               int Bq, int D) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1601,6 +1613,15 @@ hipError_t launch_gallery_gather(const void* g, const int32_t* gk, const int64_t
     if (n <= 0 || !g || !rows || !out) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gallery_gather_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const half_t*)g, gk, rows, n, D,
                        (half_t*)out, out_keys);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_gallery_scatter(const void* in, const int32_t* in_keys, const int64_t* rows, int n, int D, void* g,
+                                  int32_t* gk, hipStream_t s) {
+    if (n <= 0 || !in || !in_keys || !rows || !g || !gk || D % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gallery_scatter_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const half_t*)in, in_keys, rows, n,
+                       D, (half_t*)g, gk);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

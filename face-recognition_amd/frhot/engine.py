@@ -194,6 +194,15 @@ class Gallery:
                                            _ptr(keys, C.c_int32)))
         return out, keys
 
+    def write_f16(self, rows_f16: np.ndarray, keys, rows):
+        """Restore rows exactly as read(): fp16 unit rows [n, D], keys [n], destination rows [n]."""
+        rows_f16 = np.ascontiguousarray(rows_f16, dtype=np.float16).reshape(-1, self.dim)
+        n = rows_f16.shape[0]
+        keys = np.ascontiguousarray(np.broadcast_to(np.asarray(keys, dtype=np.int32), (n,)))
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(n)
+        check(self._lib.frhot_gallery_write_f16(self._h, C.c_void_p(rows_f16.ctypes.data), _ptr(keys, C.c_int32),
+                                                _ptr(rows, C.c_int64), n))
+
     def search(self, q: np.ndarray, qkeys=None, k: int = 5):
         """float32 queries [Bq, D] (host) -> (scores [Bq,k] f32 descending, rows [Bq,k] i64, -1 = none)."""
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.dim)

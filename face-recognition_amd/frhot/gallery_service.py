@@ -8,13 +8,17 @@ device-resident gallery (frhot.engine.Gallery) instead of Qdrant collections:
     (qdrant_database_FE/app.py:316-327) is one key comparison inside the scan;
   * the row -> (point id, payload) table, the <=10-faces-per-id eviction
     (app.py:207-240), delete-by-payload-id (app.py:409-438) and the threshold + vote
-    (app.py:340-384) stay on the host.
+    (app.py:340-384) stay on the host;
+  * per-collection snapshots (app.py:130-196) are one .npz file each: the stored fp16
+    rows read back from the device plus the point table, restored bit for bit.
 
 Methods return (status_code, content) exactly as the handlers answer.
 """
 from __future__ import annotations
 
 import datetime
+import json
+import os
 import threading
 import uuid
 
@@ -211,3 +215,78 @@ class GalleryService:
                     for i in idx:
                         out[i] = (404, {"message": str(e)})
             return out
+
+    # -------------------------------------------------------------- snapshots
+    # One file per snapshot, <dir>/<collection>/<collection>-<timestamp>.frsnap.npz, holding
+    # "rows" fp16 [n, dim] exactly as stored on the device and "points" = JSON list of
+    # {uid, payload, seq}.  Same life cycle as the reference's Qdrant snapshots.
+    def _snap_dir(self, directory, collection_name):
+        return os.path.join(directory, collection_name)
+
+    def list_snapshots(self, collection_name, directory):
+        """app.py:143-146: the snapshots of a collection, newest first."""
+        d = self._snap_dir(directory, collection_name)
+        if not os.path.isdir(d):
+            return []
+        out = []
+        for fn in sorted(os.listdir(d), reverse=True):
+            if fn.endswith(".frsnap.npz"):
+                st = os.stat(os.path.join(d, fn))
+                out.append({"name": fn, "size": st.st_size,
+                            "creation_time": datetime.datetime.fromtimestamp(st.st_mtime).isoformat()})
+        return out
+
+    def create_snapshot(self, collection_name, directory):
+        """app.py:130-141: delete the collection's old snapshots, then write a new one."""
+        with self._lock:
+            if collection_name not in self._collections:
+                return 404, {"message": "Collection name not found or invalid!"}
+            d = self._snap_dir(directory, collection_name)
+            os.makedirs(d, exist_ok=True)
+            for old in self.list_snapshots(collection_name, directory):
+                os.remove(os.path.join(d, old["name"]))
+            rows = sorted(r for r, p in self._points.items() if p["collection"] == collection_name)
+            if rows:
+                vec, _keys = self.gallery.read(np.asarray(rows, dtype=np.int64))
+            else:
+                vec = np.zeros((0, self.dim), np.float16)
+            points = [{"uid": self._points[r]["uid"], "payload": self._points[r]["payload"],
+                       "seq": self._points[r]["seq"]} for r in rows]
+            self._seq += 1
+            name = f"{collection_name}-{datetime.datetime.now().strftime('%Y-%m-%d-%H-%M-%S')}-{self._seq}.frsnap.npz"
+            path = os.path.join(d, name)
+            with open(path, "wb") as f:
+                np.savez(f, rows=np.asarray(vec, np.float16), dim=np.int64(self.dim),
+                         points=np.frombuffer(json.dumps(points).encode("utf-8"), dtype=np.uint8))
+            return 200, {"name": name, "size": os.path.getsize(path), "points": len(rows)}
+
+    def recover_snapshot(self, collection_name, path):
+        """app.py:171-196: (create the collection if missing and) replace its points by the snapshot's."""
+        try:
+            parts = collection_name.split("_")
+            if len(parts) < 2 or parts[1] not in ("Employees", "Customers"):
+                return 404, {"message": "Collection name not found or invalid!"}
+            with np.load(path, allow_pickle=False) as z:
+                vec = np.asarray(z["rows"], np.float16)
+                if int(z["dim"]) != self.dim or vec.ndim != 2 or vec.shape[1] != self.dim:
+                    return 404, {"message": "snapshot dimension does not match this gallery"}
+                points = json.loads(bytes(z["points"]).decode("utf-8"))
+            if len(points) != vec.shape[0]:
+                return 404, {"message": "snapshot is inconsistent"}
+            with self._lock:
+                self._collections.setdefault(collection_name, None)
+                self._drop_rows([r for r, p in self._points.items() if p["collection"] == collection_name])
+                rows, keys = [], []
+                for pt in points:
+                    rows.append(self._alloc_row())
+                    keys.append(self._key(collection_name, pt["payload"].get("store_id")))
+                if rows:
+                    self.gallery.write_f16(vec, np.asarray(keys, np.int32), np.asarray(rows, np.int64))
+                for r, pt in zip(rows, points):
+                    self._seq = max(self._seq, int(pt["seq"]))
+                    self._points[r] = {"uid": pt["uid"], "payload": pt["payload"], "collection": collection_name,
+                                       "seq": int(pt["seq"])}
+                    self._by_id.setdefault((collection_name, pt["payload"]["id"]), []).append(r)
+            return 200, {"message": "Recover snapshot successfully"}
+        except Exception as e:
+            return 404, {"message": str(e)}

@@ -146,6 +146,16 @@ int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, 
 /* Copy n stored rows back as fp16 [n,D] plus their keys (host buffers). */
 int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f16, int32_t* out_keys);
 
+/*
+ * Write n rows exactly as given: rows_f16 [n,D] fp16 (host; must already be unit
+ * length, nothing is normalised), keys[n] (FRHOT_KEY_DEAD allowed), destination
+ * rows[n].  The inverse of frhot_gallery_read: what one returned, this restores bit
+ * for bit.  Replaces: client.recover_snapshot of qdrant_database_FE/app.py:171-196
+ * (the point data of a collection snapshot going back into the store).
+ */
+int frhot_gallery_write_f16(frhot_gallery* g, const void* rows_f16, const int32_t* keys,
+                            const int64_t* rows, int n);
+
 /* Number of rows the scan covers: 1 + the highest row ever written. */
 int64_t frhot_gallery_rows(frhot_gallery* g);
 

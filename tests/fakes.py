@@ -27,6 +27,16 @@ class NumpyGallery:
     def tombstone(self, rows):
         self.keys[np.asarray(rows, np.int64)] = -1
 
+    def read(self, rows):
+        rows = np.asarray(rows, np.int64).reshape(-1)
+        return self.g[rows].astype(np.float16), self.keys[rows].copy()
+
+    def write_f16(self, rows_f16, keys, rows):
+        rows = np.asarray(rows, np.int64).reshape(-1)
+        self.g[rows] = np.asarray(rows_f16, np.float16).astype(np.float32).reshape(len(rows), self.dim)
+        self.keys[rows] = np.broadcast_to(np.asarray(keys, np.int32), rows.shape)
+        self.nrows = max(self.nrows, int(rows.max()) + 1)
+
     def search(self, q, qkeys=None, k=5):
         q = np.asarray(q, np.float32).reshape(-1, self.dim)
         if self.nrows == 0:

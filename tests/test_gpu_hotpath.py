@@ -280,3 +280,40 @@ def test_row_sharded_search_dev_merge(gpu_ctx):
     assert list(got_r[0, :2]) == [0, n - 1]
     for gal in shards:
         gal.close()
+
+
+def test_gallery_write_f16_restores_bit_for_bit(gpu_ctx, tmp_path):
+    """frhot_gallery_read -> frhot_gallery_write_f16 round trip, and a service snapshot restored
+    into a fresh device gallery answers every search identically."""
+    from frhot import synth
+    from frhot.engine import Gallery
+    from frhot.gallery_service import GalleryService
+    n, d = 300, 4096
+    g = synth.unit_gallery(seed=41, n=n, d=d, sparse=True)
+    gal = Gallery(gpu_ctx, d, n)
+    keys = (np.arange(n) % 3).astype(np.int32)
+    gal.upsert(g, keys, np.arange(n))
+    rows16, k16 = gal.read(np.arange(n))
+    gal2 = Gallery(gpu_ctx, d, n)
+    perm = np.random.default_rng(0).permutation(n)
+    gal2.write_f16(rows16[perm], k16[perm], perm)
+    back, kback = gal2.read(np.arange(n))
+    assert np.array_equal(back.view(np.uint16), rows16.view(np.uint16)) and np.array_equal(kback, keys)
+    q = g[:20] + 0.01
+    s1, r1 = gal.search(q, keys[:20], 5)
+    s2, r2 = gal2.search(q, keys[:20], 5)
+    assert np.array_equal(r1, r2) and np.array_equal(s1, s2)
+    gal.close()
+    gal2.close()
+    svc = GalleryService(gpu_ctx, capacity=64)
+    svc.create_collection("S9_Employees")
+    for i in range(12):
+        assert svc.insert_point("S9_Employees", list(g[i]), f"p{i % 4}", f"n{i % 4}", "S9", time_created=f"t{i:02d}")[0] == 201
+    before = [svc.search_point("S9_Employees", list(g[i]), "S9") for i in range(12)]
+    st, info = svc.create_snapshot("S9_Employees", str(tmp_path))
+    assert st == 200 and info["points"] == 12
+    svc2 = GalleryService(gpu_ctx, capacity=64)
+    assert svc2.recover_snapshot("S9_Employees", str(tmp_path / "S9_Employees" / info["name"]))[0] == 200
+    assert [svc2.search_point("S9_Employees", list(g[i]), "S9") for i in range(12)] == before
+    svc.close()
+    svc2.close()

@@ -103,6 +103,56 @@ def test_gallery_service_validation_and_eviction_order():
     assert svc._next_row <= 13
 
 
+def _same_answers(a, b, tol=2e-3):
+    """Search answers equal up to the score rounding of the stand-in gallery (it keeps float32
+    rows but snapshots carry fp16; the device gallery is fp16 throughout and round-trips exactly,
+    which tests/test_gpu_hotpath.py asserts)."""
+    assert len(a) == len(b)
+    for (sa, ca), (sb, cb) in zip(a, b):
+        assert sa == sb and ca["message"] == cb["message"] and len(ca["data"]) == len(cb["data"])
+        for (x, px), (y, py) in zip(ca["data"], cb["data"]):
+            assert px == py and abs(x - y) <= tol
+    return True
+
+
+def test_snapshot_round_trip_and_life_cycle(tmp_path):
+    """create_snapshot keeps one file per collection (the old one is deleted first, app.py:130-141);
+    recover_snapshot replaces the collection's points and leaves other collections alone."""
+    rng = np.random.default_rng(3)
+    dim = 16
+    svc = _service(dim, 64)
+    for c in ("S1_Employees", "S1_Customers"):
+        svc.create_collection(c)
+    vecs = rng.normal(size=(5, dim)).astype(np.float32)
+    for i in range(4):
+        assert svc.insert_point("S1_Employees", list(vecs[i]), f"id{i}", f"n{i}", "S1", time_created=f"t{i}")[0] == 201
+    svc.insert_point("S1_Customers", list(vecs[4]), "c0", "cust", "S1", time_created="t9")
+    st, info = svc.create_snapshot("S1_Employees", str(tmp_path))
+    assert st == 200 and info["points"] == 4
+    st, info2 = svc.create_snapshot("S1_Employees", str(tmp_path))
+    snaps = svc.list_snapshots("S1_Employees", str(tmp_path))
+    assert [x["name"] for x in snaps] == [info2["name"]]                 # the first one was deleted
+    assert svc.create_snapshot("nope_Employees", str(tmp_path))[0] == 404
+    before = [svc.search_point("S1_Employees", list(vecs[i]), "S1") for i in range(4)]
+    # mutate, then recover
+    svc.delete_point("S1_Employees", "id1")
+    svc.insert_point("S1_Employees", list(vecs[4]), "idX", "x", "S1")
+    assert svc.search_point("S1_Employees", list(vecs[1]), "S1") != before[1]
+    path = str(tmp_path / "S1_Employees" / info2["name"])
+    assert svc.recover_snapshot("S1_Employees", path) == (200, {"message": "Recover snapshot successfully"})
+    after = [svc.search_point("S1_Employees", list(vecs[i]), "S1") for i in range(4)]
+    assert _same_answers(after, before)
+    assert svc.point_count("S1_Employees") == 4 and svc.point_count("S1_Customers") == 1
+    assert svc.search_point("S1_Employees", list(vecs[4]), "S1")[1]["data"] == [] or \
+        svc.search_point("S1_Employees", list(vecs[4]), "S1")[1]["data"][0][1]["id"] != "idX"
+    # into a service that has never seen the collection (app.py:177-188 creates it)
+    svc2 = _service(dim, 64)
+    assert svc2.recover_snapshot("S1_Employees", path)[0] == 200
+    assert _same_answers([svc2.search_point("S1_Employees", list(vecs[i]), "S1") for i in range(4)], before)
+    assert svc2.recover_snapshot("Employees", path)[0] == 404            # name must be <store>_<role>
+    assert svc2.recover_snapshot("S1_Employees", str(tmp_path / "missing.npz"))[0] == 404
+
+
 def test_database_client_reshapes_like_the_reference():
     from frhot.database_client import DatabaseClient
     svc = _service(8, 32)
