@@ -1064,6 +1064,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     };
     if (!isA) phase_barrier();
     long s = 0;            // global step
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, sum_L = 0, sum_B1 = 0, sum_M = 0, sum_B2 = 0,
+                       n_units = 0;
+    (void)st_a; (void)st_b; (void)st_c; (void)st_d; (void)st_e; (void)sum_L; (void)sum_B1; (void)sum_M; (void)sum_B2;
+    (void)n_units;
+    unsigned long long sum_L2 = 0, sum_W = 0, sum_B3 = 0, sum_M2 = 0, sum_B4 = 0;
+    (void)sum_L2; (void)sum_W; (void)sum_B3; (void)sum_M2; (void)sum_B4;
     for (long item = 0; item < n_items; ++item) {
         const int slot = (int)(item & 1);
         const int chunk = (int)(item % CPK);
@@ -1073,12 +1079,24 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const char* nsrc = item_src(item + 1 < n_items ? item + 1 : item);
         auto step = [&](auto tapc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tapc)::value;
+            FR_STAMP(st_a);
             phase_L(tapc, std::integral_constant<int, 0>{}, chunk, s, slot, nsrc);
             if (NU == 2) {
+                FR_STAMP(st_b);
                 phase_barrier();
+                FR_STAMP(st_c);
                 phase_M(tapc, std::integral_constant<int, 0>{}, chunk, tile, s);
+                FR_STAMP(st_d);
                 phase_barrier();
+                FR_STAMP(st_e);
+#if FR_DBG & 8
+                sum_L += st_b - st_a; sum_B1 += st_c - st_b; sum_M += st_d - st_c; sum_B2 += st_e - st_d; ++n_units;
+#endif
                 phase_L(tapc, std::integral_constant<int, NU - 1>{}, chunk, s, slot, nsrc);
+                FR_STAMP(st_a);
+#if FR_DBG & 8
+                sum_L2 += st_a - st_e;
+#endif
             }
             // End of the step's last L phase.  Before the barrier that follows, this wave's pieces
             // of weight stage s+1 (issued in L(s-2)) and everything older (at tap 8: the next
@@ -1105,9 +1123,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(l1 + l0) : "memory");
                 }
             }
+            FR_STAMP(st_b);
             phase_barrier();
+            FR_STAMP(st_c);
             phase_M(tapc, std::integral_constant<int, NU - 1>{}, chunk, tile, s);
+            FR_STAMP(st_d);
             phase_barrier();
+            FR_STAMP(st_e);
+#if FR_DBG & 8
+            if (NU == 2) { sum_W += st_b - st_a; sum_B3 += st_c - st_b; sum_M2 += st_d - st_c; sum_B4 += st_e - st_d; }
+#endif
             ++s;
         };
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
@@ -1117,6 +1142,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         step(std::integral_constant<int, 8>{});
     }
     if (isA) phase_barrier();
+#if FR_DBG & 8
+    if (blockIdx.x == 0 && lane == 0) {
+        g_stamp[wave * 5 + 0] = sum_L; g_stamp[wave * 5 + 1] = sum_B1; g_stamp[wave * 5 + 2] = sum_M;
+        g_stamp[wave * 5 + 3] = sum_B2; g_stamp[wave * 5 + 4] = n_units;
+    }
+    if (blockIdx.x == 0 && lane == 1) {
+        g_stamp[40 + wave * 3] = sum_L2 + (sum_W << 32); g_stamp[40 + wave * 3 + 1] = sum_B3 + (sum_M2 << 32);
+        g_stamp[40 + wave * 3 + 2] = sum_B4;
+    }
+#endif
     static_assert(NCH <= 8, "chunk lists");
     if (DEFER) {    // epilogue of the last tile
         epi_chunk(std::integral_constant<int, 0>{}); epi_chunk(std::integral_constant<int, 1>{});

@@ -122,13 +122,20 @@ static void bench_conv(int B) {
         printf("%-10s %8.3f ms  %7.1f TFLOP/s   (hw %d cin %d cout %d pool %d)\n", names[i], ms, fl / ms / 1e9,
                d.hw, d.cin, d.cout, d.pool);
 #if FR_DBG & 8
-        if (i < 3) {
+        if (i >= 1 && i < 3) {
             unsigned long long st[64];
             CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(frhot::g_stamp), sizeof st));
             for (int wv = 0; wv < 8; ++wv)
-                printf("   wave %d: per item main %6.0f epi %6.0f barrier %6.0f cycles (%llu items)\n", wv,
-                       (double)st[wv * 4] / st[wv * 4 + 3], (double)st[wv * 4 + 1] / st[wv * 4 + 3],
-                       (double)st[wv * 4 + 2] / st[wv * 4 + 3], st[wv * 4 + 3]);
+                printf("   wave %d: per unit L %5.0f  barrier %5.0f  M %5.0f  barrier %5.0f cycles (%llu units)\n", wv,
+                       (double)st[wv * 5] / st[wv * 5 + 4], (double)st[wv * 5 + 1] / st[wv * 5 + 4],
+                       (double)st[wv * 5 + 2] / st[wv * 5 + 4], (double)st[wv * 5 + 3] / st[wv * 5 + 4], st[wv * 5 + 4]);
+            for (int wv = 0; wv < 8; ++wv) {
+                const double n = (double)st[wv * 5 + 4];
+                printf("   wave %d: unit 1   L %5.0f  vmwait %5.0f  barrier %5.0f  M %5.0f  barrier %5.0f\n", wv,
+                       (double)(st[40 + wv * 3] & 0xffffffffu) / n, (double)(st[40 + wv * 3] >> 32) / n,
+                       (double)(st[40 + wv * 3 + 1] & 0xffffffffu) / n, (double)(st[40 + wv * 3 + 1] >> 32) / n,
+                       (double)st[40 + wv * 3 + 2] / n);
+            }
         }
 #endif
         tot_ms += ms * reps;

@@ -138,7 +138,7 @@ static void run(const _Float16* src, float* out, int waves) {
 // Ping-pong phases with NDMA LDS-DMA pieces (1 KiB each, L2-resident source) per wave and
 // iteration, issued either in the load phase (WHERE 0), in the MFMA phase before the MFMAs
 // (WHERE 1), or spread between the MFMAs (WHERE 2).
-template <int NA, int NB, int NDMA, int WHERE, int SRC>
+template <int NA, int NB, int NDMA, int WHERE, int SRC, int LOOK = 2>
 __global__ __launch_bounds__(512) void probe_dma(const _Float16* __restrict__ src, float* __restrict__ out, int iters,
                                                   const char* __restrict__ big, size_t big_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,8 +170,14 @@ __global__ __launch_bounds__(512) void probe_dma(const _Float16* __restrict__ sr
     const size_t per_iter = (size_t)NDMA * 8 * 1024;
     const char* bsrc = big + ((size_t)blockIdx.x * 4096 * per_iter) % big_bytes + wave * NDMA * 1024 + lane * 16;
     auto dma = [&](int it, int i) {
-        const char* g = SRC == 0 ? gsrc + ((it + i) & 15) * 65536
-                                 : bsrc + (((size_t)it * per_iter) % (big_bytes / 2)) + i * 1024;
+        const char* g;
+        if (SRC == 0) g = gsrc + ((it + i) & 15) * 65536;
+        else if (SRC == 1) g = bsrc + (((size_t)it * per_iter) % (big_bytes / 2)) + i * 1024;
+        else if (SRC == 2)      // 2 MiB window per XCD, walked by its 32 blocks at staggered offsets
+            g = big + (size_t)(blockIdx.x & 7) * (2u << 20) +
+                (((size_t)it * per_iter + (size_t)(blockIdx.x >> 3) * 65536 + wave * NDMA * 1024 + i * 1024) % (2u << 20)) + lane * 16;
+        else                    // 128 MiB window shared by all blocks (Infinity Cache resident, beyond L2)
+            g = big + (((size_t)it * per_iter + (size_t)blockIdx.x * (512u << 10) + wave * NDMA * 1024 + i * 1024) % (128u << 20)) + lane * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dst + (i & 3) * 1024), 16, 0, 0);
     };
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(512) void probe_dma(const _Float16* __restrict__ sr
         for (int a = 0; a < NA; ++a) fa[a] = *(const half8*)(p + a * 2048);
 #pragma unroll
         for (int b = 0; b < NB; ++b) fb[b] = *(const half8*)(p + 32768 + b * 2048);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOOK * NDMA) : "memory");
         bar();
         if (WHERE == 1) {
 #pragma unroll
@@ -211,10 +217,10 @@ __global__ __launch_bounds__(512) void probe_dma(const _Float16* __restrict__ sr
     out[blockIdx.x * 512 + tid] = s;
 }
 
-template <int NA, int NB, int NDMA, int WHERE, int SRC>
+template <int NA, int NB, int NDMA, int WHERE, int SRC, int LOOK = 2>
 static void run_dma(const _Float16* src, float* out, const char* big, size_t big_bytes) {
     const int iters = 4096;
-    auto k = probe_dma<NA, NB, NDMA, WHERE, SRC>;
+    auto k = probe_dma<NA, NB, NDMA, WHERE, SRC, LOOK>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -229,8 +235,8 @@ static void run_dma(const _Float16* src, float* out, const char* big, size_t big
     CK(hipEventElapsedTime(&ms, a, b));
     ms /= 5;
     const double fl = 256.0 * 8 * iters * NA * NB * 16.0 * 16 * 32 * 2;
-    printf("PP NA=%d NB=%d dma/wave/iter=%d where=%d src=%d: %7.3f ms  %7.1f TFLOP/s  DMA %.0f GB/s\n", NA, NB, NDMA,
-           WHERE, SRC, ms, fl / ms / 1e9, 256.0 * 8 * iters * NDMA * 1024 / ms / 1e6);
+    printf("PP NA=%d NB=%d dma/wave/iter=%d where=%d src=%d look=%d: %7.3f ms  %7.1f TFLOP/s  DMA %.0f GB/s\n", NA, NB, NDMA,
+           WHERE, SRC, LOOK, ms, fl / ms / 1e9, 256.0 * 8 * iters * NDMA * 1024 / ms / 1e6);
 }
 
 int main() {
@@ -250,11 +256,10 @@ int main() {
     char* big;
     CK(hipMalloc((void**)&big, big_bytes));
     CK(hipMemset(big, 1, big_bytes));
-    run_dma<4, 8, 0, 0, 0>(src, out, big, big_bytes);
-    run_dma<4, 8, 4, 0, 0>(src, out, big, big_bytes); run_dma<4, 8, 8, 0, 0>(src, out, big, big_bytes);
-    run_dma<4, 8, 2, 0, 1>(src, out, big, big_bytes); run_dma<4, 8, 4, 0, 1>(src, out, big, big_bytes);
-    run_dma<4, 8, 8, 0, 1>(src, out, big, big_bytes);
-    run_dma<4, 4, 4, 0, 1>(src, out, big, big_bytes); run_dma<2, 4, 4, 0, 1>(src, out, big, big_bytes);
+    run_dma<4, 8, 8, 0, 0, 2>(src, out, big, big_bytes);
+    run_dma<4, 8, 8, 0, 2, 2>(src, out, big, big_bytes); run_dma<4, 8, 8, 0, 3, 2>(src, out, big, big_bytes);
+    run_dma<4, 8, 8, 0, 1, 2>(src, out, big, big_bytes);
+    run_dma<4, 8, 4, 0, 2, 2>(src, out, big, big_bytes); run_dma<4, 8, 4, 0, 3, 2>(src, out, big, big_bytes);
     return 0;
     run<2, 4, 0>(src, out, 8); run<2, 4, 1>(src, out, 8); run<2, 4, 2>(src, out, 8); run<2, 4, 3>(src, out, 8);
     run<4, 4, 0>(src, out, 8); run<4, 4, 1>(src, out, 8); run<4, 4, 2>(src, out, 8); run<4, 4, 3>(src, out, 8);
