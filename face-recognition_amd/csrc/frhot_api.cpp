@@ -190,7 +190,8 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
     if (c->stage_end(0) || c->stage_begin(1)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_conv1_1(c->x0, c->w[0], c->bias[0], c->act[0], B, s));
     for (int l = 1; l < kNumConv; ++l) {
-        ConvLayerDesc d{kConv[l].hw, kConv[l].cin, kConv[l].cout, kConv[l].pool, kConv[l].opad};
+        // layers alternate direction so that each starts on what its predecessor wrote last
+        ConvLayerDesc d{kConv[l].hw, kConv[l].cin, kConv[l].cout, kConv[l].pool, kConv[l].opad, l & 1};
         HIP_TRY(launch_conv3x3(d, c->act[l - 1], c->w[l], c->bias[l], c->act[l], c->partial, B, s));
     }
     if (c->stage_end(1) || c->stage_begin(2)) return fail(FRHOT_EHIP, "event record failed");

@@ -23,6 +23,7 @@ struct ConvLayerDesc {
     int cin, cout;
     int pool;     // 1: 2x2/2 max-pool fused into the epilogue
     int opad;     // 1: output carries a zero halo of one pixel
+    int reverse;  // 1: walk the pixel tiles from the last image to the first (cache reuse across layers)
 };
 
 hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const uint8_t* lut,

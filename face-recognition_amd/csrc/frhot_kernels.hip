@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
                                                            const half_t* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            half_t* __restrict__ y, half_t* __restrict__ dump,
-                                                           int batch) {
+                                                           int batch, int reverse) {
     using Core = GemmCore8<256, RY, WX, WY, false>;
     constexpr int H = HW, W = HW, PW = W + 2, HALF = W / 2;
     constexpr int K = 9 * CIN, CPK = CIN / 64, NK = 9 * CPK;
@@ -646,8 +646,13 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
 
     const char* xp[Core::NPX];
     const char* yp[Core::NPY];
+    // `reverse` walks the pixel tiles from the last image to the first: a layer then starts on
+    // the part of its input that the previous layer wrote last and that the 256 MiB Infinity
+    // Cache still holds (layers alternate direction)
+    const long nmt = (M + 255) / 256;
     auto set_pixels = [&](long tile) {
-        const long m0 = (tile / NT) * 256;
+        const long mt = tile / NT;
+        const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
 #pragma unroll
         for (int i = 0; i < Core::NPX; ++i) {
             long m = m0 + Core::stage_row(wave, lane, i);
@@ -720,7 +725,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
         core.compute(xs + xslot * Core::XB, ys + yslot * Core::YB, lane, wx, wy);
         const bool tile_end = (ks == NK - 1);
         if (tile_end) {
-            const long m0 = (tile / NT) * 256;
+            const long mt = tile / NT;
+            const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
 #pragma unroll
             for (int px = 0; px < NX; ++px) {
                 const long m = m0 + wx * Core::TX + px * 16 + l15;
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
                                                             const half_t* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             half_t* __restrict__ y, half_t* __restrict__ dump,
-                                                            int batch) {
+                                                            int batch, int reverse) {
     static_assert(WX * WY == 8 && HW % 16 == 0 && CIN % 64 == 0 && COUT % RY == 0 && RY % 64 == 0, "shape");
     constexpr int PW = 18, NPIECE = 41, PATCH_B = NPIECE * 1024;
     constexpr int CPK = CIN / 64, NKS = 9 * CPK, K = 9 * CIN;
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     auto item_src = [&](long item) __attribute__((always_inline)) -> const char* {
         const long tile = wk + (item / CPK) * G;
         const int c = (int)(item % CPK);
-        const long st = tile / NT;
+        const long st = reverse ? (long)batch * TPI - 1 - tile / NT : tile / NT;   // see conv3x3_ring_kernel
         const int b = (int)(st / TPI), rem = (int)(st % TPI);
         const int ty = rem / TPR, tx = rem - ty * TPR;
         return (const char*)x + ((((long)b * IW + ty * 16) * IW + tx * 16) * CIN + c * 64) * 2;
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     half_t* pend = dump + lane * 8;     // where chunk stores of the pending tile go; dump: no tile pending
     long pend_stride_on = 0;            // 1 once a real tile is pending (0 keeps every chunk inside dump)
     auto tile_out = [&](long tile) __attribute__((always_inline)) -> half_t* {
-        const long st = tile / NT;
+        const long st = reverse ? (long)batch * TPI - 1 - tile / NT : tile / NT;
         const int b = (int)(st / TPI), rem = (int)(st % TPI);
         const int ty = rem / TPR, tx = rem - ty * TPR;
         const int a0 = wx * NX;
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
 
 template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY>
 static hipError_t launch_patch_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
-                                    hipStream_t s, bool set_attr_only) {
+                                    int reverse, hipStream_t s, bool set_attr_only) {
     auto kern = conv3x3_patch_kernel<HW, CIN, COUT, POOL, RY, WX, WY>;
     constexpr int patch2 = 2 * 41 * 1024, nks = 9 * CIN / 64, yb = RY * 128;
     constexpr bool res = nks * yb + patch2 <= 160 * 1024;
@@ -1501,14 +1507,14 @@ static hipError_t launch_patch_inst(const void* x, const void* w, const float* b
     long grid = 256;                       // one walker per CU; a multiple of COUT / RY
     if (grid > ntiles) grid = ntiles;      // ntiles is a multiple of NT
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
-                       (half_t*)y, (half_t*)dump, B);
+                       (half_t*)y, (half_t*)dump, B, reverse);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
 
 template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RY, int WX, int WY>
 static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
-                                   hipStream_t s, bool set_attr_only) {
+                                   int reverse, hipStream_t s, bool set_attr_only) {
     using Core = GemmCore8<256, RY, WX, WY, false>;
     auto kern = conv3x3_ring_kernel<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>;
     constexpr int lds = Core::LDS;
@@ -1519,7 +1525,7 @@ static hipError_t launch_conv_inst(const void* x, const void* w, const float* bi
     long grid = 256;                       // one walker per CU; a multiple of COUT / RY
     if (grid > ntiles) grid = (ntiles + 1) & ~1L;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
-                       (half_t*)y, (half_t*)dump, B);
+                       (half_t*)y, (half_t*)dump, B, reverse);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
@@ -1528,10 +1534,10 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
                                 void* dump, int B, hipStream_t s, bool attr) {
 #define FR_CONV(HW, CIN, COUT, POOL, OPAD, RY, WX, WY)                                                       \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD)           \
-        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>(x, w, bias, y, dump, B, s, attr);
+        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>(x, w, bias, y, dump, B, d.reverse, s, attr);
 #define FR_PATCH(HW, CIN, COUT, POOL, RY, WX, WY)                                                            \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == 1)              \
-        return launch_patch_inst<HW, CIN, COUT, POOL, RY, WX, WY>(x, w, bias, y, dump, B, s, attr);
+        return launch_patch_inst<HW, CIN, COUT, POOL, RY, WX, WY>(x, w, bias, y, dump, B, d.reverse, s, attr);
     FR_PATCH(224, 64, 64, true, 64, 4, 2)
     FR_PATCH(112, 64, 128, false, 128, 4, 2)
     FR_PATCH(112, 128, 128, true, 128, 4, 2)
