@@ -91,6 +91,23 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     }, {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
 
 
+def pmc_traffic(rows, dim, queries, k):
+    """HBM bytes per launch of the scan for this exact workload, from the newest committed PMC
+    summary (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this bench, FETCH_SIZE doubled for gfx950).  None when no pass covers the workload."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for ent in doc.get("kernels", {}).values():
+            if ent.get("workload") == {"rows": rows, "dim": dim, "queries": queries, "k": k}:
+                return ent["traffic_bytes"], f"{doc.get('source', os.path.basename(path))} ({doc.get('correction', '')})"
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,9 +201,11 @@ def main():
             ms64 = ctx.stage_ms()["scan"]
             ctx.timing(False)
             b64 = n64 * D * 2 + bq64 * D * 2
+            tr64, src64 = pmc_traffic(n64, D, bq64, k64)
             scan64 = {"workload": f"scan only: {n64}x{D} fp16 gallery, {bq64} queries, top-{k64}", "bound": "hbm",
                       "achieved": b64 / (ms64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                      "frac": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr64,
+                      "traffic_source": src64,
                       "algorithmic_bytes_per_launch": b64, "ms_per_launch": ms64,
                       "queries_per_s": bq64 / (ms64 * 1e-3)}
             gal64.close()
@@ -195,7 +214,9 @@ def main():
         if rank == 0:
             ms_step = elapsed / args.steps * 1e3
             faces = P * B * args.steps
-            scan_bytes = rows_local * D * 2 + rows_local * 4 + P * B * D * 2
+            # no key filter in this workload: the scan reads the rows and the queries, not the keys
+            scan_bytes = rows_local * D * 2 + P * B * D * 2
+            traffic, traffic_src = pmc_traffic(rows_local, D, P * B, K)
             scan_gbs = scan_bytes / (stages["scan"] * 1e-3) / 1e9 if stages["scan"] > 0 else 0.0
             scan_tf = 2.0 * P * B * rows_local * D / (stages["scan"] * 1e-3) / 1e12 if stages["scan"] > 0 else 0.0
             cnn_ms = stages["conv"] + stages["fc"]
@@ -210,7 +231,8 @@ def main():
                            "batch_per_gpu": B, "gallery_rows": args.gallery_rows, "dim": D, "k": K,
                            "parallelism": f"dp{P}+rowshard{P}"},
                 "roofline": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_source": traffic_src,
                              "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": stages["scan"],
                              "mfma_tflops": scan_tf, "mfma_frac": scan_tf / MFMA_PEAK_TFLOPS,
                              "note": ("at P*B = %d queries the scan's intensity (~Bq flop/B) sits at the HBM/MFMA "
