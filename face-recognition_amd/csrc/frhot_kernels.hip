@@ -17,13 +17,19 @@
 #include <type_traits>
 #include "frhot_kernels.h"
 
+#ifndef FR_LOOP_MIN_K
+#define FR_LOOP_MIN_K 10
+#endif
+#ifndef FR_SCAN_PP
+#define FR_SCAN_PP false
+#endif
 #ifndef FR_DBG
-#define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps
+#define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps (patch conv), 32 in-kernel stamps (scan)
 #endif
 
 namespace frhot {
 
-#if FR_DBG & 8
+#if FR_DBG & (8 | 32)
 __device__ unsigned long long g_stamp[64];
 #define FR_STAMP(var)                                                                        \
     do {                                                                                     \
@@ -582,6 +588,42 @@ struct GemmCore8 {
     FR_DEV static void wait_keep_newest() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     FR_DEV static void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+    // Software-pipelined form of one K-step: four units u = (kk, xh) of NY * NX/2 MFMAs each
+    // (kk = 32-deep half of the step, xh = half of the streamed rows).  The resident fragments
+    // of a kk are read once and kept for both of its units; the streamed fragments alternate
+    // between two sets, so unit u+1's reads are in flight while unit u's MFMAs issue.
+    static constexpr int NXH = NX / 2;
+    half8 pfy[2][NY], pfx[2][NXH];
+    template <int U>
+    FR_DEV void read_unit(const char* xbuf, const char* ybuf, int lane, int wx, int wy) {
+        constexpr int kk = U >> 1, xh = U & 1;
+        const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+        const int coff = (((kk * 4 + g0) ^ l7) << 4);
+        if (xh == 0) {
+#pragma unroll
+            for (int y = 0; y < NY; ++y)
+                pfy[kk][y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
+        }
+#pragma unroll
+        for (int x = 0; x < NXH; ++x)
+            pfx[xh][x] = *(const half8*)(xbuf + (wx * TX + (xh * NXH + x) * 16 + l15) * 128 + coff);
+    }
+    template <int U>
+    FR_DEV void mma_unit() {
+        constexpr int kk = U >> 1, xh = U & 1;
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int x = 0; x < NXH; ++x) {
+                if (X_IS_A)
+                    acc[y][xh * NXH + x] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(pfx[xh][x], pfy[kk][y], acc[y][xh * NXH + x], 0, 0, 0);
+                else
+                    acc[y][xh * NXH + x] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_f16(pfy[kk][y], pfx[xh][x], acc[y][xh * NXH + x], 0, 0, 0);
+            }
+    }
+
     FR_DEV void compute(const char* xbuf, const char* ybuf, int lane, int wx, int wy) {
         const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
 #pragma unroll
@@ -644,8 +686,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     const int cb = Core::stage_chunk_bytes(lane);
     const int n0 = (wk % NT) * RY;     // G is a multiple of NT: the channel tile never changes
 
-    const char* xp[Core::NPX];
-    const char* yp[Core::NPY];
+    // per-lane byte offsets into x and w (both far below 4 GiB for the layers this kernel serves);
+    // the uniform part of an address stays in scalar registers
+    unsigned xo[Core::NPX], yo[Core::NPY];
     // `reverse` walks the pixel tiles from the last image to the first: a layer then starts on
     // the part of its input that the previous layer wrote last and that the 256 MiB Infinity
     // Cache still holds (layers alternate direction)
@@ -661,7 +704,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
             const int rem = (int)(m % (H * W));
             const int win = rem >> 2, d = rem & 3;
             const int py = 2 * (win / HALF) + (d >> 1), px = 2 * (win % HALF) + (d & 1);
-            xp[i] = (const char*)x + ((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb;
+            xo[i] = (unsigned)(((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb);
         }
     };
     // LDS row r of the weight tile holds output channel n0 + chan(r), permuted so that the
@@ -672,7 +715,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
         const int r = Core::stage_row(wave, lane, i);
         const int in = r % Core::TY, cy = in >> 4, g = (in >> 2) & 3, j = in & 3;
         const int ch = (r / Core::TY) * Core::TY + (cy >> 1) * 32 + g * 8 + (cy & 1) * 4 + j;
-        yp[i] = (const char*)w + ((long)(n0 + ch) * K) * 2 + cb;
+        yo[i] = (unsigned)(((long)(n0 + ch) * K) * 2 + cb);
     }
 
     // Bias of this lane's channels, fetched and waited for before the pipeline starts: an
@@ -692,8 +735,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     // the XCD's L2 still holds them (with the taps outermost the re-reads were CIN/64 steps apart
     // and a round's working set exceeded the 4 MiB L2).
     auto next_x = [&](int slot) {
-        const size_t off = ((size_t)(ir * PW + is) * CIN + icc * 64) * 2;
-        Core::issue_x(xs + slot * Core::XB, wave, xp, off);
+        const char* const base = (const char*)x + ((size_t)(ir * PW + is) * CIN + icc * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < Core::NPX; ++i) glds16(base + xo[i], xs + slot * Core::XB + (wave + 8 * i) * 1024);
         if (++is == 3) {
             is = 0;
             if (++ir == 3) {
@@ -704,7 +748,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     };
     int ytap = 0, ycc = 0;
     auto next_y = [&](int slot) {
-        Core::issue_y(ys + slot * Core::YB, wave, yp, ((size_t)ytap * CIN + ycc * 64) * 2);
+        const char* const base = (const char*)w + ((size_t)ytap * CIN + ycc * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < Core::NPY; ++i) glds16(base + yo[i], ys + slot * Core::YB + (wave + 8 * i) * 1024);
         if (++ytap == 9) { ytap = 0; if (++ycc == CPK) ycc = 0; }
     };
 
@@ -719,67 +765,95 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     constexpr int OW = WO + 2 * OPAD, OH = HO + 2 * OPAD;
     int xslot = 0, yslot = 0, ks = 0;
     long tile = wk;
+    // epilogue of the tile whose last step has just been accumulated
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const long mt = tile / NT;
+        const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
+#pragma unroll
+        for (int px = 0; px < NX; ++px) {
+            const long m = m0 + wx * Core::TX + px * 16 + l15;
+            const bool live = m < M;
+            const long mm = live ? m : M - 1;
+            const int b = (int)(mm / (H * W));
+            const int rem = (int)(mm % (H * W));
+            const int win = rem >> 2, d = rem & 3;
+            int oy, ox;
+            if (POOL) { oy = win / HALF; ox = win % HALF; }
+            else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
+            half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
+#pragma unroll
+            for (int u = 0; u < NY / 2; ++u) {
+                const int c = n0 + wy * Core::TY + u * 32 + g0 * 8;
+                half8 o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4v v = core.acc[2 * u + h][px];
+                    if (POOL) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float t = v[j];
+                            t = fmaxf(t, __shfl_xor(t, 1));
+                            t = fmaxf(t, __shfl_xor(t, 2));
+                            v[j] = t;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[4 * h + j] = (half_t)fmaxf(v[j] + bv[2 * u + h][j], 0.f);
+                }
+                // Every wave issues this store (dead pixels go to `dump`): the counted wait
+                // below relies on a fixed number of vector-memory ops per step.  Pooled
+                // layers store from the quad leader only; its EXEC is never empty.
+                half_t* dst = live ? orow + c : dump + lane * 8;
+                if (!POOL || (lane & 3) == 0) *(half8*)dst = o;
+            }
+        }
+        core.zero();
+        tile += G;
+    };
+    auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    auto reads_done = [&]() __attribute__((always_inline)) {
+        fence(); __builtin_amdgcn_s_waitcnt(0xC07F); fence();       // lgkmcnt(0)
+    };
+    // Pipeline across the step barrier: a step's unit 3 is issued after the barrier that opens the
+    // next step, behind that step's first fragment reads, so the MFMA pipe has work while the reads
+    // are in flight.  A tile's epilogue follows its last unit 3, at the head of the next step; its
+    // stores are older than every load issued afterwards, so the counted wait at the step's end
+    // (only the newest streamed stage stays in flight) also retires them.
     for (long s = 0; s < S; ++s) {
+        const char* const xbuf = xs + xslot * Core::XB;
+        const char* const ybuf = ys + yslot * Core::YB;
+        core.template read_unit<0>(xbuf, ybuf, lane, wx, wy);
+        fence();
+        if (s > 0) {
+            core.template mma_unit<3>();
+            fence();
+            if (ks == NK) { epilogue(); ks = 0; }
+        }
         if (s + 1 < S) next_y(yslot ^ 1);
         if (s + 2 < S) next_x(xslot == 0 ? 2 : xslot - 1);
-        core.compute(xs + xslot * Core::XB, ys + yslot * Core::YB, lane, wx, wy);
-        const bool tile_end = (ks == NK - 1);
-        if (tile_end) {
-            const long mt = tile / NT;
-            const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
-#pragma unroll
-            for (int px = 0; px < NX; ++px) {
-                const long m = m0 + wx * Core::TX + px * 16 + l15;
-                const bool live = m < M;
-                const long mm = live ? m : M - 1;
-                const int b = (int)(mm / (H * W));
-                const int rem = (int)(mm % (H * W));
-                const int win = rem >> 2, d = rem & 3;
-                int oy, ox;
-                if (POOL) { oy = win / HALF; ox = win % HALF; }
-                else { oy = 2 * (win / HALF) + (d >> 1); ox = 2 * (win % HALF) + (d & 1); }
-                half_t* orow = y + (((long)b * OH + oy + OPAD) * OW + ox + OPAD) * COUT;
-#pragma unroll
-                for (int u = 0; u < NY / 2; ++u) {
-                    const int c = n0 + wy * Core::TY + u * 32 + g0 * 8;
-                    half8 o;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float4v v = core.acc[2 * u + h][px];
-                        if (POOL) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float t = v[j];
-                                t = fmaxf(t, __shfl_xor(t, 1));
-                                t = fmaxf(t, __shfl_xor(t, 2));
-                                v[j] = t;
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[4 * h + j] = (half_t)fmaxf(v[j] + bv[2 * u + h][j], 0.f);
-                    }
-                    // Every wave issues this store (dead pixels go to `dump`): the counted wait
-                    // below relies on a fixed number of vector-memory ops per step.  Pooled
-                    // layers store from the quad leader only; its EXEC is never empty.
-                    half_t* dst = live ? orow + c : dump + lane * 8;
-                    if (!POOL || (lane & 3) == 0) *(half8*)dst = o;
-                }
-            }
-            core.zero();
-            ks = 0; tile += G;
-        } else {
-            ++ks;
-        }
-        if (s + 2 < S) {
-            if (tile_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
-            else Core::wait_keep_newest();
-        } else {
-            Core::wait_all();
-        }
+        reads_done();
+        core.template read_unit<1>(xbuf, ybuf, lane, wx, wy);
+        fence();
+        core.template mma_unit<0>();
+        reads_done();
+        core.template read_unit<2>(xbuf, ybuf, lane, wx, wy);
+        fence();
+        core.template mma_unit<1>();
+        reads_done();
+        core.template read_unit<3>(xbuf, ybuf, lane, wx, wy);
+        fence();
+        core.template mma_unit<2>();
+        ++ks;
+        reads_done();      // every read of this step's stages has returned: the stages may be refilled
+        if (s + 2 < S) Core::wait_keep_newest();
+        else Core::wait_all();
         __builtin_amdgcn_s_barrier();
+        fence();
         xslot = xslot == 2 ? 0 : xslot + 1;
         yslot ^= 1;
     }
+    core.template mma_unit<3>();
+    epilogue();
 }
 
 // 3x3 convolution with the input PATCH resident in LDS (layers whose height is a multiple
@@ -1281,6 +1355,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         half8 fx[U][NX], fy[U][NY];
         int xslot = 0, yslot = 0, ks = 0;
         long tile = gb;
+#if FR_DBG & 32
+        unsigned long long sum_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         for (long s = 0; s < S; ++s) {
             const char* const xbuf = xs + xslot * XB;
             const char* const ybuf = ys + yslot * YB;
@@ -1312,12 +1389,25 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         for (int x = 0; x < NX; ++x)
                             acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[k2][x], fy[k2][y], acc[y][x], 0, 0, 0);
             };
+#if FR_DBG & 32
+            unsigned long long st0, st1, st2, st3, st4, st5, st6, st7;
+            FR_STAMP(st0);
+#endif
             phase_L(std::integral_constant<int, 0>{});
+#if FR_DBG & 32
+            FR_STAMP(st1); st2 = st1; st3 = st1;
+#endif
             if (NU == 2) {
                 if (PP) phase_barrier();
                 phase_M();
+#if FR_DBG & 32
+                FR_STAMP(st2);
+#endif
                 if (PP) phase_barrier();
                 phase_L(std::integral_constant<int, NU - 1>{});
+#if FR_DBG & 32
+                FR_STAMP(st3);
+#endif
             }
             // Gallery step s+1 and query slice s+1 must have landed before the next step reads them
             // (with the ping-pong schedule group A does so two phases on, hence the wait sits before
@@ -1330,6 +1420,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
             };
             if (PP) { step_wait(); phase_barrier(); }
             phase_M();
+#if FR_DBG & 32
+            FR_STAMP(st4);
+#endif
             if (ks == nk - 1) {
                 const long rbase = tile * 256 + wx * TX + g0 * 4;
                 const bool partial = (tile + 1) * 256 > nrows;
@@ -1355,24 +1448,33 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                             v[x][j] = ok ? acc[y][x][j] : -INFINITY;
                         }
                     }
-                    float m = -INFINITY;
+                    if constexpr (K < FR_LOOP_MIN_K) {
+                        // short lists: one branch per 16-row block, taken only when some lane of the
+                        // wave holds a qualifying score among the block's four (late in the scan most
+                        // blocks are skipped); inside, straight-line predicated insertion
 #pragma unroll
-                    for (int x = 0; x < NX; ++x) m = fmaxf(fmaxf(m, fmaxf(v[x][0], v[x][1])), fmaxf(v[x][2], v[x][3]));
-                    // Slow path, taken while any lane still holds a score that belongs in its list:
-                    // each lane inserts its best remaining score (equal scores: lowest row first, the
-                    // order the list expects), strikes it out and looks for the next.  The cost follows
-                    // the number of real candidates per lane, not the tile's 4*NX scores.
-                    if constexpr (K < 10) {
-                        // short lists: straight-line predicated insertion of every qualifying score
-                        if (m >= thr && m > top[y].s[K - 1]) {
-#pragma unroll
-                            for (int x = 0; x < NX; ++x)
+                        for (int x = 0; x < NX; ++x) {
+                            const float mx = fmaxf(fmaxf(v[x][0], v[x][1]), fmaxf(v[x][2], v[x][3]));
+#if FR_DBG & 64
+                            if (mx == 12345.f) top[y].s[0] = mx;
+                            continue;
+#endif
+                            if (mx >= thr && mx > top[y].s[K - 1]) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
                                     if (v[x][j] >= thr && v[x][j] > top[y].s[K - 1])
                                         top[y].template push<false>(v[x][j], (int)(rbase + x * 16 + j));
+                            }
                         }
-                    } else
+                        continue;
+                    }
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) m = fmaxf(fmaxf(m, fmaxf(v[x][0], v[x][1])), fmaxf(v[x][2], v[x][3]));
+                    // Long lists, taken while any lane still holds a score that belongs in its list:
+                    // each lane inserts its best remaining score (equal scores: lowest row first, the
+                    // order the list expects), strikes it out and looks for the next.  The cost follows
+                    // the number of real candidates per lane, not the tile's 4*NX scores.
                     while (__any(m >= thr && m > top[y].s[K - 1])) {
                         const bool want = m >= thr && m > top[y].s[K - 1];
                         int hit = -1;
@@ -1401,12 +1503,27 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
             } else {
                 ++ks;
             }
+#if FR_DBG & 32
+            FR_STAMP(st5);
+#endif
             if (!PP) step_wait();
+#if FR_DBG & 32
+            FR_STAMP(st6);
+#endif
             phase_barrier();
+#if FR_DBG & 32
+            FR_STAMP(st7);
+            sum_st[0] += st1 - st0; sum_st[1] += st2 - st1; sum_st[2] += st3 - st2; sum_st[3] += st4 - st3;
+            sum_st[4] += st5 - st4; sum_st[5] += st6 - st5; sum_st[6] += st7 - st6; sum_st[7] += 1;
+#endif
             xslot = xslot == XS - 1 ? 0 : xslot + 1;
             yslot = yslot == YS - 1 ? 0 : yslot + 1;
         }
         if (PP && isA) phase_barrier();
+#if FR_DBG & 32
+        if (blockIdx.x == 8 && lane == 0)
+            for (int i = 0; i < 8; ++i) g_stamp[wave * 8 + i] = sum_st[i];
+#endif
     }
 
     // merge the WX*4 lists of each query through LDS, one thread per query
@@ -1693,7 +1810,7 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     constexpr int merge = RY * WX * 4 * K * 8;
     constexpr int lds = ring > merge ? ring : merge;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS, false>;
+    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS, FR_SCAN_PP>;
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,

@@ -260,7 +260,6 @@ int main() {
     run_dma<4, 8, 8, 0, 2, 2>(src, out, big, big_bytes); run_dma<4, 8, 8, 0, 3, 2>(src, out, big, big_bytes);
     run_dma<4, 8, 8, 0, 1, 2>(src, out, big, big_bytes);
     run_dma<4, 8, 4, 0, 2, 2>(src, out, big, big_bytes); run_dma<4, 8, 4, 0, 3, 2>(src, out, big, big_bytes);
-    return 0;
     run<2, 4, 0>(src, out, 8); run<2, 4, 1>(src, out, 8); run<2, 4, 2>(src, out, 8); run<2, 4, 3>(src, out, 8);
     run<4, 4, 0>(src, out, 8); run<4, 4, 1>(src, out, 8); run<4, 4, 2>(src, out, 8); run<4, 4, 3>(src, out, 8);
     run<4, 8, 0>(src, out, 8); run<4, 8, 1>(src, out, 8); run<4, 8, 2>(src, out, 8); run<4, 8, 3>(src, out, 8);
