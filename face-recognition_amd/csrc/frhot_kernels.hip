@@ -20,16 +20,13 @@
 #ifndef FR_LOOP_MIN_K
 #define FR_LOOP_MIN_K 10
 #endif
-#ifndef FR_SCAN_PP
-#define FR_SCAN_PP false
-#endif
 #ifndef FR_DBG
-#define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps (patch conv), 32 in-kernel stamps (scan)
+#define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps (patch conv)
 #endif
 
 namespace frhot {
 
-#if FR_DBG & (8 | 32)
+#if FR_DBG & 8
 __device__ unsigned long long g_stamp[64];
 #define FR_STAMP(var)                                                                        \
     do {                                                                                     \
@@ -521,6 +518,21 @@ __global__ __launch_bounds__(256) void f32_to_unit_f16_kernel(const float* __res
 }
 
 // ------------------------------------------------------------ scan+top-k ---
+// max / min over the four lanes l, l^16, l^32, l^48 (the lanes that hold one MFMA output column),
+// through the row-swap instructions: no LDS round trip
+FR_DEV float lanes4_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+FR_DEV float lanes4_min(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <int K>
 struct TopK {
     float s[K];
@@ -1247,14 +1259,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
 // gallery allocation is padded to whole tiles, so loads never leave it; rows >= nrows are
 // masked in the last tile.  Ring depths are chosen per query tile so that the LDS is used up:
 // the gallery stream runs XS-1 steps ahead (HBM latency), the query slices YS-1 steps (L2).
-// PP selects the ping-pong schedule (waves 0..3 and 4..7 one barrier-delimited phase apart, one
-// group reading fragments and issuing LDS-DMA while the other runs MFMAs); measured on MI355X
-// it is 5-10 % slower than the lock-step schedule for this kernel, whose steps are paced by the
-// arrival of HBM data rather than by instruction issue, so the library instantiates PP = false.
+// A ping-pong schedule (waves 0..3 and 4..7 one barrier-delimited phase apart) and a software-
+// pipelined K-step were both measured slower than this lock-step one for this kernel.
 // Top-k: every lane keeps a sorted list per query column; before a tile's 4*NX new scores are
 // examined, the four lanes that share a query exchange their k-th best: a score below the best
 // of those can never reach the final list.
-template <int K, int RY, int WX, int WY, bool USE_KEYS, bool PP>
+template <int K, int RY, int WX, int WY, bool USE_KEYS>
 __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict__ gal,
                                                            const int32_t* __restrict__ gkeys, long nrows, int D,
                                                            const half_t* __restrict__ q,
@@ -1266,8 +1276,8 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     constexpr int XS = RY <= 64 ? 4 : 3, YS = RY <= 128 ? 3 : 2;
     constexpr int DX = XS - 1, DY = YS - 1;
     constexpr int NPX = 4, NPY = RY / 64;
-    constexpr int U = (NX * NY >= 16) ? 1 : 2, NU = 2 / U;
-    // loads that may stay in flight at the end of a step's last L phase (see the wait below)
+    constexpr int XSPLIT = 1, NXH = NX / XSPLIT, NUN = 2 * XSPLIT;     // 2 halves the fragment registers, ~4 % slower
+    // loads that may stay in flight at the end of a step (see the wait below)
     constexpr int INFLIGHT = (DX == 3 && DY == 2) ? 2 * NPX + NPY : (DX == 2 && DY == 2) ? NPX + NPY : NPX;
     static_assert((DX == 3 && DY == 2) || (DX == 2 && DY == 2) || (DX == 2 && DY == 1), "ring depths");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1287,23 +1297,14 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     const long S = my_tiles * nk;
     const int cb = ((l7 ^ (lane >> 3)) << 4);
 
-    const char* xp[NPX];
-    const char* yp[NPY];
-#pragma unroll
-    for (int i = 0; i < NPX; ++i)
-        xp[i] = (const char*)gal + (size_t)(8 * (wave + 8 * i) + (lane >> 3)) * D * 2 + cb;
-#pragma unroll
-    for (int i = 0; i < NPY; ++i) {
-        int qq = q0 + 8 * (wave + 8 * i) + (lane >> 3);
-        qq = qq < Bq ? qq : Bq - 1;
-        yp[i] = (const char*)q + (size_t)qq * D * 2 + cb;
-    }
-    int mykey[NY];
-#pragma unroll
-    for (int y = 0; y < NY; ++y) {
-        const int qq = q0 + wy * TY + y * 16 + l15;
-        mykey[y] = (USE_KEYS && qkeys && qq < Bq) ? qkeys[qq] : -2;
-    }
+    // Per-lane byte offsets of this lane's 16 B inside a gallery tile / the query block (the host
+    // checks that both stay below 4 GiB).  Piece i of a stage is 64 rows further on, a uniform
+    // distance that goes into the scalar part of the address, so one register serves all pieces;
+    // query rows past Bq are clamped to the last row (their columns are never written out).
+    const unsigned xo0 = (unsigned)((8 * wave + (lane >> 3)) * D * 2 + cb);
+    const unsigned yo0 = (unsigned)(q0 + 8 * wave + (lane >> 3)) * (unsigned)D * 2u + (unsigned)cb;
+    const unsigned yomax = (unsigned)(Bq - 1) * (unsigned)D * 2u + (unsigned)cb;
+    const unsigned pstride = 64u * (unsigned)D * 2u;
     TopK<K> top[NY];
 #pragma unroll
     for (int y = 0; y < NY; ++y) top[y].init();
@@ -1318,19 +1319,27 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         long itile = gb; int iks = 0;   // next gallery step to issue
         int yks = 0;                    // next query slice to issue
         auto issue_x = [&](int slot) __attribute__((always_inline)) {
-            const size_t off = ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
+            const char* const base = (const char*)gal + ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
 #pragma unroll
             // with one query tile every gallery byte is read by one CU, once: stream it non-temporally
             // (+3..6 % on the HBM-bound shapes); with several, the other tiles' blocks want it in L2
             for (int i = 0; i < NPX; ++i) {
-                if (qtiles == 1) glds16_nt(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
-                else glds16(xp[i] + off, xs + slot * XB + (wave + 8 * i) * 1024);
+                unsigned o = xo0;
+                asm volatile("" : "+v"(o));     // keeps the 64-bit sum out of loop-invariant registers
+                if (qtiles == 1) glds16_nt(base + (size_t)i * pstride + o, xs + slot * XB + (wave + 8 * i) * 1024);
+                else glds16(base + (size_t)i * pstride + o, xs + slot * XB + (wave + 8 * i) * 1024);
             }
             if (++iks == nk) { iks = 0; itile += nb; }
         };
         auto issue_y = [&](int slot) __attribute__((always_inline)) {
+            unsigned yb = yo0;
+            asm volatile("" : "+v"(yb));        // as above: the clamped offsets are recomputed, not kept
 #pragma unroll
-            for (int i = 0; i < NPY; ++i) glds16(yp[i] + (size_t)yks * 128, ys + slot * YB + (wave + 8 * i) * 1024);
+            for (int i = 0; i < NPY; ++i) {
+                unsigned o = yb + (unsigned)i * pstride;
+                o = o < yomax ? o : yomax;
+                glds16((const char*)q + (size_t)yks * 128 + o, ys + slot * YB + (wave + 8 * i) * 1024);
+            }
             if (++yks == nk) yks = 0;
         };
         auto phase_barrier = [&]() __attribute__((always_inline)) {
@@ -1350,127 +1359,157 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        const bool isA = wave < 4;
-        if (PP && !isA) phase_barrier();      // group B runs one phase behind group A from here on
-        half8 fx[U][NX], fy[U][NY];
+        // A step runs as NUN units u = (kk, xh): kk = 32-deep half of the step, xh = 1/XSPLIT of the
+        // gallery rows.  The query fragments of a kk are read with its first unit and kept; the large
+        // tile splits the rows so that the fragments of a unit fit beside 128 accumulators and the
+        // top-k lists.
+        half8 fx[NXH], fy[NY];
         int xslot = 0, yslot = 0, ks = 0;
         long tile = gb;
-#if FR_DBG & 32
-        unsigned long long sum_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
         for (long s = 0; s < S; ++s) {
             const char* const xbuf = xs + xslot * XB;
             const char* const ybuf = ys + yslot * YB;
-            auto phase_L = [&](auto uc) __attribute__((always_inline)) {
-                constexpr int u = decltype(uc)::value;
+            auto unit = [&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value, kk = u / XSPLIT, xh = u % XSPLIT;
                 if (u == 0) {
                     if (s + DY < S) issue_y(yslot == 0 ? YS - 1 : yslot - 1);
                 }
-                if (u == NU - 1) {
+                if (u == NUN - 1) {
                     if (s + DX < S) issue_x(xslot == 0 ? XS - 1 : xslot - 1);
                 }
+                const int coff = (((kk * 4 + g0) ^ l7) << 4);
+                if (xh == 0) {
 #pragma unroll
-                for (int k2 = 0; k2 < U; ++k2) {
-                    const int coff = ((((u * U + k2) * 4 + g0) ^ l7) << 4);
+                    for (int y = 0; y < NY; ++y) fy[y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
+                }
+#pragma unroll
+                for (int x = 0; x < NXH; ++x)
+                    fx[x] = *(const half8*)(xbuf + (wx * TX + (xh * NXH + x) * 16 + l15) * 128 + coff);
+                // a tile's first MFMAs start from zero instead of from cleared accumulators
+                if (kk == 0 && ks == 0) {
+                    const float4v zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int y = 0; y < NY; ++y)
-                        fy[k2][y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
 #pragma unroll
-                    for (int x = 0; x < NX; ++x)
-                        fx[k2][x] = *(const half8*)(xbuf + (wx * TX + x * 16 + l15) * 128 + coff);
+                        for (int x = 0; x < NXH; ++x)
+                            acc[y][xh * NXH + x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], zero, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int y = 0; y < NY; ++y)
+#pragma unroll
+                        for (int x = 0; x < NXH; ++x)
+                            acc[y][xh * NXH + x] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], acc[y][xh * NXH + x], 0, 0, 0);
                 }
             };
-            auto phase_M = [&]() __attribute__((always_inline)) {
+            unit(std::integral_constant<int, 0>{});
+            unit(std::integral_constant<int, 1>{});
+            if constexpr (NUN == 4) {
+                unit(std::integral_constant<int, 2>{});
+                unit(std::integral_constant<int, 3>{});
+            }
+            if (ks == nk - 1) {
+                const int rbase = (int)(tile * 256) + wx * TX + g0 * 4;     // rows fit 31 bits (checked at launch)
+                // Rows whose key does not match the query's, and rows past the end of the gallery (last
+                // tile only), are struck out of the accumulators in place (the next tile starts
+                // from zero anyway): the selection then reads the accumulators themselves and needs no copy.
+                // Key test: (key ^ kx) <= km as unsigned, with (kx, km) = (query key, 0) for an exact
+                // match and (0, 0x7fffffff) for "any live row" (tombstones are negative).
+                if (USE_KEYS) {
+                    int4 kv[NX];
 #pragma unroll
-                for (int k2 = 0; k2 < U; ++k2)
+                    for (int x = 0; x < NX; ++x) kv[x] = *(const int4*)(gkeys + rbase + x * 16);   // padded allocation: in bounds
+                    // the queries' keys are fetched here, once per tile, rather than kept in registers
+                    int mykey[NY];
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        const int qq = q0 + wy * TY + y * 16 + l15;
+                        mykey[y] = (qkeys && qq < Bq) ? qkeys[qq] : -2;
+                    }
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned kx = mykey[y] == -2 ? 0u : (unsigned)mykey[y];
+                        const unsigned km = mykey[y] == -2 ? 0x7fffffffu : 0u;
+#pragma unroll
+                        for (int x = 0; x < NX; ++x) {
+                            const unsigned k4[4] = {(unsigned)kv[x].x, (unsigned)kv[x].y, (unsigned)kv[x].z, (unsigned)kv[x].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[y][x][j] = ((k4[j] ^ kx) <= km) ? acc[y][x][j] : -INFINITY;
+                        }
+                    }
+                }
+                if ((tile + 1) * 256 > nrows) {
+                    const int nr = (int)nrows;
 #pragma unroll
                     for (int y = 0; y < NY; ++y)
 #pragma unroll
                         for (int x = 0; x < NX; ++x)
-                            acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[k2][x], fy[k2][y], acc[y][x], 0, 0, 0);
-            };
-#if FR_DBG & 32
-            unsigned long long st0, st1, st2, st3, st4, st5, st6, st7;
-            FR_STAMP(st0);
-#endif
-            phase_L(std::integral_constant<int, 0>{});
-#if FR_DBG & 32
-            FR_STAMP(st1); st2 = st1; st3 = st1;
-#endif
-            if (NU == 2) {
-                if (PP) phase_barrier();
-                phase_M();
-#if FR_DBG & 32
-                FR_STAMP(st2);
-#endif
-                if (PP) phase_barrier();
-                phase_L(std::integral_constant<int, NU - 1>{});
-#if FR_DBG & 32
-                FR_STAMP(st3);
-#endif
-            }
-            // Gallery step s+1 and query slice s+1 must have landed before the next step reads them
-            // (with the ping-pong schedule group A does so two phases on, hence the wait sits before
-            // the barrier that ends this L phase).  In issue order the later of the two is followed
-            // only by the loads counted in INFLIGHT, which may stay outstanding; near the end of the
-            // block's work fewer loads are issued, so everything is waited for.
-            auto step_wait = [&]() __attribute__((always_inline)) {
-                if (s + DX < S && s + DY < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            };
-            if (PP) { step_wait(); phase_barrier(); }
-            phase_M();
-#if FR_DBG & 32
-            FR_STAMP(st4);
-#endif
-            if (ks == nk - 1) {
-                const long rbase = tile * 256 + wx * TX + g0 * 4;
-                const bool partial = (tile + 1) * 256 > nrows;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[y][x][j] = (rbase + x * 16 + j < nr) ? acc[y][x][j] : -INFINITY;
+                }
 #pragma unroll
                 for (int y = 0; y < NY; ++y) {
-                    float thr = top[y].s[K - 1];
-                    thr = fmaxf(thr, __shfl_xor(thr, 16));
-                    thr = fmaxf(thr, __shfl_xor(thr, 32));
-                    float v[NX][4];
+                    // one query column group at a time: interleaving the groups would need their
+                    // temporaries live together, beside 128 accumulators and the lists
+                    __builtin_amdgcn_sched_barrier(0);
+                    // Lower bounds on the K-th best score of the query over the four lanes' lists:
+                    // (a) any lane's own K-th best; (b) min(best (KA+1)-th of any lane, worst
+                    // (KB+1)-th of all lanes): the lane that supplies the first term holds KA+1
+                    // scores at or above it and each other lane KB+1, K or more in all.
+                    constexpr int KB = (K - 1) / 5, KA = K - 3 * (KB + 1) - 1;
+                    static_assert(KA >= KB && KA < K && (KA + 1) + 3 * (KB + 1) >= K, "threshold bound");
+                    float thr = lanes4_max(top[y].s[K - 1]);
+                    thr = fmaxf(thr, fminf(lanes4_max(top[y].s[KA]), lanes4_min(top[y].s[KB])));
+                    float4v (&v)[NX] = acc[y];        // struck-out entries may be overwritten: the next tile starts from zero
+                    // best and second best of the lane's 4*NX scores, branch-free
+                    float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
-                    for (int x = 0; x < NX; ++x) {
-                        const long r0 = rbase + x * 16;
-                        int kk[4] = {0, 0, 0, 0};
-                        if (USE_KEYS) {
-                            const int4 kv = *(const int4*)(gkeys + r0);   // padded allocation: in bounds
-                            kk[0] = kv.x; kk[1] = kv.y; kk[2] = kv.z; kk[3] = kv.w;
-                        }
+                    for (int x = 0; x < NX; ++x)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            bool ok = true;
-                            if (USE_KEYS) ok = (mykey[y] == -2) ? kk[j] >= 0 : kk[j] == mykey[y];
-                            if (partial) ok = ok && (r0 + j < nrows);
-                            v[x][j] = ok ? acc[y][x][j] : -INFINITY;
+                            m2 = fmaxf(m2, fminf(m1, v[x][j]));
+                            m1 = fmaxf(m1, v[x][j]);
                         }
+                    const bool q1 = m1 >= thr && m1 > top[y].s[K - 1];
+                    if (!__any(q1)) continue;                  // the common case late in the scan
+                    if (!__any(m2 >= thr && m2 > top[y].s[K - 1])) {
+                        // no lane holds two qualifying scores (the usual case otherwise): one
+                        // insertion per lane, of its best; the lowest row among equal scores
+                        int hit = 0;
+#pragma unroll
+                        for (int x = NX - 1; x >= 0; --x)
+#pragma unroll
+                            for (int j = 3; j >= 0; --j)
+                                if (v[x][j] == m1) hit = x * 16 + j;
+                        if (q1) top[y].template push<false>(m1, (int)rbase + hit);
+                        continue;
                     }
                     if constexpr (K < FR_LOOP_MIN_K) {
                         // short lists: one branch per 16-row block, taken only when some lane of the
-                        // wave holds a qualifying score among the block's four (late in the scan most
-                        // blocks are skipped); inside, straight-line predicated insertion
+                        // wave holds a qualifying score among the block's four; inside, the lane's
+                        // best of the four is inserted and struck out until none qualifies
 #pragma unroll
                         for (int x = 0; x < NX; ++x) {
                             const float mx = fmaxf(fmaxf(v[x][0], v[x][1]), fmaxf(v[x][2], v[x][3]));
-#if FR_DBG & 64
-                            if (mx == 12345.f) top[y].s[0] = mx;
-                            continue;
-#endif
                             if (mx >= thr && mx > top[y].s[K - 1]) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (v[x][j] >= thr && v[x][j] > top[y].s[K - 1])
-                                        top[y].template push<false>(v[x][j], (int)(rbase + x * 16 + j));
+                                // Nearly always one of the lane's four scores qualifies: insert the
+                                // best (lowest row first among equal scores, the order the list
+                                // expects), strike it out and look again.
+                                float c0 = v[x][0], c1 = v[x][1], c2 = v[x][2], c3 = v[x][3], cm = mx;
+                                do {
+                                    const int jb = c0 == cm ? 0 : c1 == cm ? 1 : c2 == cm ? 2 : 3;
+                                    top[y].template push<false>(cm, (int)(rbase + x * 16) + jb);
+                                    c0 = jb == 0 ? -INFINITY : c0; c1 = jb == 1 ? -INFINITY : c1;
+                                    c2 = jb == 2 ? -INFINITY : c2; c3 = jb == 3 ? -INFINITY : c3;
+                                    cm = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3));
+                                } while (cm >= thr && cm > top[y].s[K - 1]);
                             }
                         }
                         continue;
                     }
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int x = 0; x < NX; ++x) m = fmaxf(fmaxf(m, fmaxf(v[x][0], v[x][1])), fmaxf(v[x][2], v[x][3]));
+                    float m = m1;
                     // Long lists, taken while any lane still holds a score that belongs in its list:
                     // each lane inserts its best remaining score (equal scores: lowest row first, the
                     // order the list expects), strikes it out and looks for the next.  The cost follows
@@ -1495,35 +1534,20 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         m = want ? m2 : -INFINITY;     // a lane with nothing to insert is done with this tile
                     }
                 }
-#pragma unroll
-                for (int y = 0; y < NY; ++y)
-#pragma unroll
-                    for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
                 ks = 0; tile += nb;
             } else {
                 ++ks;
             }
-#if FR_DBG & 32
-            FR_STAMP(st5);
-#endif
-            if (!PP) step_wait();
-#if FR_DBG & 32
-            FR_STAMP(st6);
-#endif
+            // Gallery step s+1 and query slice s+1 must have landed before the next step reads them.
+            // In issue order the later of the two is followed only by the loads counted in INFLIGHT,
+            // which may stay outstanding; near the end of the block's work fewer loads are issued,
+            // so everything is waited for.
+            if (s + DX < S && s + DY < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             phase_barrier();
-#if FR_DBG & 32
-            FR_STAMP(st7);
-            sum_st[0] += st1 - st0; sum_st[1] += st2 - st1; sum_st[2] += st3 - st2; sum_st[3] += st4 - st3;
-            sum_st[4] += st5 - st4; sum_st[5] += st6 - st5; sum_st[6] += st7 - st6; sum_st[7] += 1;
-#endif
             xslot = xslot == XS - 1 ? 0 : xslot + 1;
             yslot = yslot == YS - 1 ? 0 : yslot + 1;
         }
-        if (PP && isA) phase_barrier();
-#if FR_DBG & 32
-        if (blockIdx.x == 8 && lane == 0)
-            for (int i = 0; i < 8; ++i) g_stamp[wave * 8 + i] = sum_st[i];
-#endif
     }
 
     // merge the WX*4 lists of each query through LDS, one thread per query
@@ -1810,7 +1834,7 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     constexpr int merge = RY * WX * 4 * K * 8;
     constexpr int lds = ring > merge ? ring : merge;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS, FR_SCAN_PP>;
+    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS>;
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,
@@ -1844,6 +1868,8 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
     if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q ||
         !part_s || !part_r || !nblk_out || (use_keys && !gk))
         return hipErrorInvalidValue;
+    // the kernel addresses the query block and a gallery tile with 32-bit lane offsets
+    if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
     const int kl = scan_klist(k);
     const int ry = scan_query_tile(Bq, kl);
     const int qtiles = (Bq + ry - 1) / ry;

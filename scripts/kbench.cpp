@@ -14,7 +14,7 @@
 #include "../face-recognition_amd/csrc/frhot_kernels.h"
 
 using namespace frhot;
-#if FR_DBG & (8 | 32)
+#if FR_DBG & 8
 namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
 #endif
 
@@ -172,18 +172,6 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
     const double fl = 2.0 * Bq * (double)N * D;
     printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d\n",
            N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk);
-#if FR_DBG & 32
-    {
-        unsigned long long st[64];
-        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(frhot::g_stamp), sizeof st));
-        for (int wv = 0; wv < 8; ++wv) {
-            const double n = (double)st[wv * 8 + 7];
-            printf("   wave %d per step: L0 %5.0f  M0 %5.0f  L1 %5.0f  M1 %5.0f  topk %5.0f  vmwait %5.0f  barrier %5.0f  (%.0f steps)\n",
-                   wv, st[wv * 8] / n, st[wv * 8 + 1] / n, st[wv * 8 + 2] / n, st[wv * 8 + 3] / n, st[wv * 8 + 4] / n,
-                   st[wv * 8 + 5] / n, st[wv * 8 + 6] / n, n);
-        }
-    }
-#endif
     CK(hipFree(g)); CK(hipFree(gk)); CK(hipFree(q)); CK(hipFree(ps)); CK(hipFree(pr));
     if (qk) CK(hipFree(qk));
 }
