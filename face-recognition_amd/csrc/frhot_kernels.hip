@@ -26,7 +26,7 @@
 
 namespace frhot {
 
-#if FR_DBG & 8
+#if FR_DBG & (8 | 32)
 __device__ unsigned long long g_stamp[64];
 #define FR_STAMP(var)                                                                        \
     do {                                                                                     \
@@ -749,7 +749,11 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     auto next_x = [&](int slot) {
         const char* const base = (const char*)x + ((size_t)(ir * PW + is) * CIN + icc * 64) * 2;
 #pragma unroll
-        for (int i = 0; i < Core::NPX; ++i) glds16(base + xo[i], xs + slot * Core::XB + (wave + 8 * i) * 1024);
+        for (int i = 0; i < Core::NPX; ++i) {
+            unsigned o = xo[i];
+            asm volatile("" : "+v"(o));     // keeps the 64-bit sum out of loop-invariant registers
+            glds16(base + o, xs + slot * Core::XB + (wave + 8 * i) * 1024);
+        }
         if (++is == 3) {
             is = 0;
             if (++ir == 3) {
@@ -762,7 +766,11 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     auto next_y = [&](int slot) {
         const char* const base = (const char*)w + ((size_t)ytap * CIN + ycc * 64) * 2;
 #pragma unroll
-        for (int i = 0; i < Core::NPY; ++i) glds16(base + yo[i], ys + slot * Core::YB + (wave + 8 * i) * 1024);
+        for (int i = 0; i < Core::NPY; ++i) {
+            unsigned o = yo[i];
+            asm volatile("" : "+v"(o));
+            glds16(base + o, ys + slot * Core::YB + (wave + 8 * i) * 1024);
+        }
         if (++ytap == 9) { ytap = 0; if (++ycc == CPK) ycc = 0; }
     };
 
@@ -830,7 +838,14 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     // next step, behind that step's first fragment reads, so the MFMA pipe has work while the reads
     // are in flight.  A tile's epilogue follows its last unit 3, at the head of the next step; its
     // stores are older than every load issued afterwards, so the counted wait at the step's end
-    // (only the newest streamed stage stays in flight) also retires them.
+    // (only the newest streamed stage stays in flight) also retires them.  The step's eight LDS-DMA
+    // instructions per wave are issued together at its head: the CU's vector-memory path accepts one
+    // 1 KiB instruction per ~16 cycles, and spreading them between the MFMA units (two per unit)
+    // or staggering the two wave groups measured 3-6 % slower.
+#if FR_DBG & 32
+    unsigned long long dsum[7] = {0, 0, 0, 0, 0, 0, 0}, tprev;
+    FR_STAMP(tprev);
+#endif
     for (long s = 0; s < S; ++s) {
         const char* const xbuf = xs + xslot * Core::XB;
         const char* const ybuf = ys + yslot * Core::YB;
@@ -844,28 +859,53 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
         if (s + 1 < S) next_y(yslot ^ 1);
         if (s + 2 < S) next_x(xslot == 0 ? 2 : xslot - 1);
         reads_done();
+#if FR_DBG & 32
+        unsigned long long ta, tb, tc, td, te, tf;
+        FR_STAMP(ta);
+#endif
         core.template read_unit<1>(xbuf, ybuf, lane, wx, wy);
         fence();
         core.template mma_unit<0>();
         reads_done();
+#if FR_DBG & 32
+        FR_STAMP(tb);
+#endif
         core.template read_unit<2>(xbuf, ybuf, lane, wx, wy);
         fence();
         core.template mma_unit<1>();
         reads_done();
+#if FR_DBG & 32
+        FR_STAMP(tc);
+#endif
         core.template read_unit<3>(xbuf, ybuf, lane, wx, wy);
         fence();
         core.template mma_unit<2>();
         ++ks;
         reads_done();      // every read of this step's stages has returned: the stages may be refilled
+#if FR_DBG & 32
+        FR_STAMP(td);
+#endif
         if (s + 2 < S) Core::wait_keep_newest();
         else Core::wait_all();
+#if FR_DBG & 32
+        FR_STAMP(te);
+#endif
         __builtin_amdgcn_s_barrier();
         fence();
+#if FR_DBG & 32
+        FR_STAMP(tf);
+        dsum[0] += ta - tprev; dsum[1] += tb - ta; dsum[2] += tc - tb; dsum[3] += td - tc; dsum[4] += te - td;
+        dsum[5] += tf - te; dsum[6] += 1; tprev = tf;
+#endif
         xslot = xslot == 2 ? 0 : xslot + 1;
         yslot ^= 1;
     }
     core.template mma_unit<3>();
     epilogue();
+#if FR_DBG & 32
+    if (blockIdx.x == 8 && lane == 0)
+        for (int i = 0; i < 7; ++i) g_stamp[wave * 8 + i] = dsum[i];
+#endif
 }
 
 // 3x3 convolution with the input PATCH resident in LDS (layers whose height is a multiple

@@ -14,7 +14,7 @@
 #include "../face-recognition_amd/csrc/frhot_kernels.h"
 
 using namespace frhot;
-#if FR_DBG & 8
+#if FR_DBG & (8 | 32)
 namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
 #endif
 
@@ -135,6 +135,18 @@ static void bench_conv(int B) {
                        (double)(st[40 + wv * 3] & 0xffffffffu) / n, (double)(st[40 + wv * 3] >> 32) / n,
                        (double)(st[40 + wv * 3 + 1] & 0xffffffffu) / n, (double)(st[40 + wv * 3 + 1] >> 32) / n,
                        (double)st[40 + wv * 3 + 2] / n);
+            }
+        }
+#endif
+#if FR_DBG & 32
+        if (i >= 3) {
+            unsigned long long st[64];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(frhot::g_stamp), sizeof st));
+            for (int wv = 0; wv < 8; wv += 4) {
+                const double n = (double)st[wv * 8 + 6];
+                printf("   wave %d per step: head(R0,M3,epi,DMA) %5.0f  u0 %5.0f  u1 %5.0f  u2 %5.0f  vmwait %5.0f  barrier %5.0f  (%.0f steps)\n",
+                       wv, st[wv * 8] / n, st[wv * 8 + 1] / n, st[wv * 8 + 2] / n, st[wv * 8 + 3] / n, st[wv * 8 + 4] / n,
+                       st[wv * 8 + 5] / n, n);
             }
         }
 #endif
