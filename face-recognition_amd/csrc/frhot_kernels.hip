@@ -432,15 +432,18 @@ __global__ __launch_bounds__(256) void gallery_upsert_kernel(const float* __rest
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const float* v = vecs + (size_t)i * D;
-    float ss = 0.f;
-    for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
+    // norm from a double-precision sum of squares, rounded to float, then one IEEE division per
+    // element: the stored row is then the same whatever the summation order (what a float32
+    // cosine collection keeps, rounded once more to fp16)
+    double ss = 0.0;
+    for (int c = lane; c < D; c += 64) ss += (double)v[c] * (double)v[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float nrm = __fsqrt_rn(ss);
-    const float inv = nrm < 1e-30f ? 1.0f : __fdiv_rn(1.0f, nrm);
+    float nrm = (float)sqrt(ss);
+    nrm = nrm < 1e-30f ? 1.0f : nrm;
     const int64_t r = rows ? rows[i] : i;
     half_t* dst = g + (size_t)r * D;
-    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fmul_rn(v[c], inv);
+    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fdiv_rn(v[c], nrm);
     if (lane == 0 && gk) gk[r] = keys ? keys[i] : 0;
 }
 
@@ -508,13 +511,13 @@ __global__ __launch_bounds__(256) void f32_to_unit_f16_kernel(const float* __res
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= Bq) return;
     const float* v = q + (size_t)i * D;
-    float ss = 0.f;
-    for (int c = lane; c < D; c += 64) ss += v[c] * v[c];
+    double ss = 0.0;            // as gallery_upsert_kernel
+    for (int c = lane; c < D; c += 64) ss += (double)v[c] * (double)v[c];
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) ss += __shfl_xor(ss, o2);
-    const float nrm = __fsqrt_rn(ss);
-    const float inv = nrm < 1e-30f ? 1.0f : __fdiv_rn(1.0f, nrm);
-    for (int c = lane; c < D; c += 64) o[(size_t)i * D + c] = (half_t)__fmul_rn(v[c], inv);
+    float nrm = (float)sqrt(ss);
+    nrm = nrm < 1e-30f ? 1.0f : nrm;
+    for (int c = lane; c < D; c += 64) o[(size_t)i * D + c] = (half_t)__fdiv_rn(v[c], nrm);
 }
 
 // ------------------------------------------------------------ scan+top-k ---

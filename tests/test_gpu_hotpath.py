@@ -121,7 +121,8 @@ def _check_topk(got_s, got_r, ref_s, ref_r, full_scores=None, tol=1e-4):
             assert (got_r[i, j] >= 0) == (ref_r[i, j] >= 0), f"query {i} slot {j}: presence differs"
             # a differing slot must hold a row whose oracle score ties the oracle's slot score
             assert full_scores is not None
-            assert abs(full_scores[i, got_r[i, j]] - ref_s[i, j]) <= tol, \
+            sc = full_scores(i, got_r[i, j]) if callable(full_scores) else full_scores[i, got_r[i, j]]
+            assert abs(sc - ref_s[i, j]) <= tol, \
                 f"query {i} slot {j}: row {got_r[i, j]} vs {ref_r[i, j]} is not a tie"
     ok = np.isfinite(ref_s)
     assert np.abs(got_s[ok] - ref_s[ok]).max() <= tol
@@ -150,6 +151,50 @@ def test_search_matches_oracle(gpu_ctx, n, d, bq, k):
     _check_topk(got_s, got_r, ref_s32, ref_r32, full32, tol=1e-4)
     if n >= k:
         assert (got_r[:, 0] == targets).mean() >= 0.9 or d < 256
+    gal.close()
+
+
+@pytest.mark.parametrize("n,d,bq,k,with_keys", [(600_000, 64, 256, 5, False), (400_000, 128, 300, 10, True),
+                                                 (300_000, 64, 64, 16, False), (500_000, 64, 256, 5, True),
+                                                 (262_144 + 77, 192, 129, 5, False)])
+def test_search_long_scan_matches_oracle(gpu_ctx, n, d, bq, k, with_keys):
+    """Many gallery tiles per block (the running top-k lists, their pruning thresholds and the
+    merge of 256 block lists all matter), every query-tile width, duplicates that tie, a key filter
+    with tombstones, and a last tile that is partly past the end of the gallery."""
+    from frhot import synth
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    rng = np.random.default_rng(n + d)
+    g = rng.standard_normal((n, d), dtype=np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    dup = rng.integers(0, n, size=(200, 2))
+    g[dup[:, 0]] = g[dup[:, 1]]                              # exact duplicates anywhere in the scan order
+    targets = rng.integers(0, n, size=bq)
+    q = synth.planted_queries(rng, g[targets], 0.7)
+    q[-1] = g[dup[0, 1]]                                     # a query whose best two rows tie exactly
+    keys = rng.integers(0, 3, size=n).astype(np.int32) if with_keys else None
+    qkeys = None
+    gal = Gallery(gpu_ctx, d, n)
+    step = 100_000
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        gal.upsert(g[lo:hi], keys[lo:hi] if with_keys else 0, np.arange(lo, hi))
+    if with_keys:
+        qkeys = keys[targets].copy()
+        qkeys[::7] = -2                                      # ANY
+        dead = rng.integers(0, n, size=5000)
+        gal.tombstone(dead)
+        keys = keys.copy()
+        keys[dead] = -1
+    got_s, got_r = gal.search(q, qkeys, k)
+    ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys, qkeys=qkeys, gallery_dtype=np.float16)
+    qn = osr.unit_rows(q).astype(np.float16).astype(np.float32)
+
+    def score(i, row):
+        return float(qn[i] @ osr.unit_rows(g[row:row + 1]).astype(np.float16).astype(np.float32)[0])
+
+    _check_topk(got_s, got_r, ref_s, ref_r, score, tol=2e-5)
+    assert (got_r >= 0).all()
     gal.close()
 
 
