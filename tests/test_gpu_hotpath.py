@@ -109,6 +109,30 @@ def test_embed_batch_invariance(gpu_ctx):
     assert np.array_equal(a[2:3], c)
 
 
+def test_embed_full_batch(gpu_ctx, weights_f32):
+    """The benchmark's batch (256 crops, several tiles per block in every layer, both tile walk
+    directions): every descriptor equals, bit for bit, the one the same crop gets in a small batch,
+    and a sample meets the cosine tolerance against the oracle."""
+    from frhot import synth
+    from frhot.engine import Context
+    from frhot.weights import pack_blob
+    from oracle import preprocess as op, vggface
+    imgs = synth.crops(seed=77, n=256, lo=112, hi=300)
+    big = Context(device=0, max_batch=256)
+    big.load_model(pack_blob(weights_f32), input_scale=1.0 / 16.0)
+    got = big.embed(imgs, gamma=True)
+    big.close()
+    assert got.shape == (256, 4096) and np.isfinite(got).all()
+    assert np.allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=1e-5)
+    pick = [0, 1, 15, 16, 100, 127, 128, 200, 254, 255]
+    small = gpu_ctx.embed([imgs[i] for i in pick], gamma=True)
+    assert np.array_equal(small, got[pick])
+    sample = [0, 128, 255]
+    x = np.stack([op.preprocess(imgs[i], apply_gamma=True) for i in sample])
+    ref = vggface.embed(x, weights_f32)
+    assert cosine_rows(got[sample], ref).min() >= 0.9999
+
+
 def _check_topk(got_s, got_r, ref_s, ref_r, full_scores=None, tol=1e-4):
     """Identical id lists except inside score ties within tol."""
     assert got_r.shape == ref_r.shape
@@ -189,6 +213,10 @@ def test_search_long_scan_matches_oracle(gpu_ctx, n, d, bq, k, with_keys):
     got_s, got_r = gal.search(q, qkeys, k)
     ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys, qkeys=qkeys, gallery_dtype=np.float16)
     qn = osr.unit_rows(q).astype(np.float16).astype(np.float32)
+    # the stored rows are the oracle's fp16 unit rows, bit for bit
+    sample = rng.integers(0, n, size=2000)
+    stored, _ = gal.read(sample)
+    assert np.array_equal(stored.view(np.uint16), osr.unit_rows(g[sample]).astype(np.float16).view(np.uint16))
 
     def score(i, row):
         return float(qn[i] @ osr.unit_rows(g[row:row + 1]).astype(np.float16).astype(np.float32)[0])
@@ -325,6 +353,48 @@ def test_row_sharded_search_dev_merge(gpu_ctx):
     assert list(got_r[0, :2]) == [0, n - 1]
     for gal in shards:
         gal.close()
+
+
+def test_full_size_scan_properties(gpu_ctx):
+    """The benchmark's gallery (10 M x 512 fp16, 256 queries, top-5), checked through properties
+    that need no CPU pass over 10 GB: a stored row asked for comes back first with score 1 (its
+    planted duplicate second, lower row first); scores descend; every returned score is the dot
+    product of the row it names; a permutation of the queries permutes the answers; the k-th score is not beaten by any row of a random sample."""
+    from frhot.engine import Gallery
+    n, d, bq, k = 10_000_000, 512, 256, 5
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=0xFACE0100, row0=0, n=n, nkeys=0, dup_every=100)   # row 100j+99 copies 100j+98
+    rng = np.random.default_rng(5)
+    asked = rng.integers(0, n, size=bq)
+    asked[:8] = [0, 98, 99, n - 1, n - 2, 255, 256, 9_999_898]
+    rows16, _ = gal.read(asked)
+    q = rows16.astype(np.float32)
+    s, r = gal.search(q, None, k)
+    assert (np.diff(s, axis=1) <= 0).all() and (r >= 0).all()
+    twin = np.where(asked % 100 == 98, asked + 1, np.where(asked % 100 == 99, asked - 1, -1))
+    for i in range(bq):
+        if twin[i] < 0:
+            assert r[i, 0] == asked[i]
+        else:
+            assert list(r[i, :2]) == sorted([asked[i], twin[i]])
+    norms = (rows16.astype(np.float64) ** 2).sum(1)
+    assert np.abs(s[:, 0] - norms).max() <= 2e-3               # fp16 unit rows: |row|^2 within rounding of 1
+    back, _ = gal.read(r.reshape(-1))
+    q16 = q / np.sqrt((q.astype(np.float64) ** 2).sum(1, keepdims=True)).astype(np.float32)
+    q16 = q16.astype(np.float16).astype(np.float32)
+    redo = (back.astype(np.float32).reshape(bq, k, d) * q16[:, None, :]).sum(-1)
+    assert np.abs(redo - s).max() <= 2e-5
+    perm = rng.permutation(bq)
+    s2, r2 = gal.search(q[perm], None, k)
+    assert np.array_equal(r2, r[perm]) and np.array_equal(s2, s[perm])
+    probe = rng.integers(0, n, size=20000)
+    pr, _ = gal.read(probe)
+    ps = q16[:32] @ pr.astype(np.float32).T
+    assert (ps.max(axis=1) <= s[:32, 0] + 2e-5).all()
+    for i in range(32):
+        beat = probe[ps[i] > s[i, k - 1] + 2e-5]
+        assert np.isin(beat, r[i]).all()
+    gal.close()
 
 
 def test_gallery_write_f16_restores_bit_for_bit(gpu_ctx, tmp_path):
