@@ -17,13 +17,25 @@ def _crops():
     imgs.append(synth.crop(rng, 601, 97))       # tall: horizontal padding, truncated dsize
     imgs.append(np.ones((64, 80, 3), np.uint8)) # max <= 1: DeepFace skips the /255
     imgs.append(np.zeros((50, 50, 3), np.uint8))
+    imgs.append(synth.crop(rng, 1, 1))          # one pixel
+    imgs.append(synth.crop(rng, 2, 3))
+    imgs.append(synth.crop(rng, 3, 500))        # fits to one row of 224 pixels, 223 rows of padding
+    imgs.append(synth.crop(rng, 447, 449))      # almost the 2x case: must take the bilinear path
+    imgs.append(synth.crop(rng, 225, 223))      # almost the identity
+    imgs.append(synth.crop(rng, 1500, 1400))    # more than 6x down: plain bilinear taps, no area averaging
+    imgs.append(np.full((300, 200, 3), 255, np.uint8))
     return imgs
 
 
 @pytest.mark.parametrize("gamma,flip", [(False, True), (True, True), (True, False)])
 def test_preprocess_exact(gpu_ctx, gamma, flip):
     from oracle import preprocess as op
-    imgs = _crops()
+    crops = _crops()
+    for lo in range(0, len(crops), 9):
+        _check_preprocess(gpu_ctx, op, crops[lo:lo + 9], gamma, flip)
+
+
+def _check_preprocess(gpu_ctx, op, imgs, gamma, flip):
     gpu_ctx.embed(imgs, gamma=gamma, flip=flip)
     u8 = gpu_ctx.debug_read(0, len(imgs))
     x0 = gpu_ctx.debug_read(1, len(imgs))
