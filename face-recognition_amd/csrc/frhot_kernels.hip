@@ -1634,21 +1634,35 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < K; ++i) { s[i] = -INFINITY; r[i] = -1; }
     const int total = nlists * kin;
-    for (int c = lane; c < total; c += 64) {
-        const int p = c / kin, j = c % kin;
-        const size_t a = ((size_t)p * Bq + qi) * kin + j;
-        const float v = cs[a];
-        const long long rr = cr[a];
-        if (rr < 0) continue;
-        const bool beats = v > s[K - 1] || (v == s[K - 1] && (r[K - 1] < 0 || rr < r[K - 1]));
-        if (!beats) continue;
-        s[K - 1] = v; r[K - 1] = rr;
+    // twenty candidates per lane are fetched before any is examined: the kernel is a handful of
+    // waves, so its time is the number of dependent memory round trips
+    constexpr int NB = 20;
+    for (int c0 = lane; c0 < total; c0 += 64 * NB) {
+        float bv[NB]; long long br[NB];
 #pragma unroll
-        for (int i = K - 1; i > 0; --i) {
-            const bool sw = s[i] > s[i - 1] || (s[i] == s[i - 1] && (r[i - 1] < 0 || r[i] < r[i - 1]));
-            const float ts = s[i - 1]; const long long tr = r[i - 1];
-            s[i - 1] = sw ? s[i] : ts; r[i - 1] = sw ? r[i] : tr;
-            s[i] = sw ? ts : s[i];     r[i] = sw ? tr : r[i];
+        for (int t = 0; t < NB; ++t) {
+            const int c = c0 + 64 * t;
+            const int cc = c < total ? c : lane;
+            const int p = cc / kin, j = cc % kin;
+            const size_t a = ((size_t)p * Bq + qi) * kin + j;
+            bv[t] = cs[a];
+            br[t] = c < total ? cr[a] : -1;
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const float v = bv[t];
+            const long long rr = br[t];
+            if (rr < 0) continue;
+            const bool beats = v > s[K - 1] || (v == s[K - 1] && (r[K - 1] < 0 || rr < r[K - 1]));
+            if (!beats) continue;
+            s[K - 1] = v; r[K - 1] = rr;
+#pragma unroll
+            for (int i = K - 1; i > 0; --i) {
+                const bool sw = s[i] > s[i - 1] || (s[i] == s[i - 1] && (r[i - 1] < 0 || r[i] < r[i - 1]));
+                const float ts = s[i - 1]; const long long tr = r[i - 1];
+                s[i - 1] = sw ? s[i] : ts; r[i - 1] = sw ? r[i] : tr;
+                s[i] = sw ? ts : s[i];     r[i] = sw ? tr : r[i];
+            }
         }
     }
     for (int o = 0; o < kout; ++o) {
