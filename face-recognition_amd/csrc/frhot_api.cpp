@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/frhot.h"
@@ -100,6 +101,7 @@ struct frhot_ctx {
     float* partial = nullptr;    // split-K partial sums
     // host-call staging
     uint8_t* crops_dev = nullptr; size_t crops_cap = 0;
+    uint8_t* crops_pin = nullptr; size_t crops_pin_cap = 0;   // page-locked mirror of crops_dev
     float* emb_dev = nullptr;    // [B,4096]
     void* q_dev = nullptr;       // fp16 [B,4096]
     int32_t* qkeys_dev = nullptr;
@@ -225,11 +227,53 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
         HIP_TRY(hipMalloc((void**)&c->crops_dev, cap));
         c->crops_cap = cap;
     }
-    for (int i = 0; i < B; ++i) {
-        const int h = hw[2 * i], w = hw[2 * i + 1];
-        HIP_TRY(hipMemcpy2DAsync(c->crops_dev + offsets[i], (size_t)3 * w, crops[i], (size_t)strides[i], (size_t)3 * w,
-                                 (size_t)h, hipMemcpyHostToDevice, c->stream));
+    if (total > c->crops_pin_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->crops_pin) HIP_TRY(hipHostFree(c->crops_pin));
+        c->crops_pin = nullptr; c->crops_pin_cap = 0;
+        const size_t cap = total + total / 4 + 4096;
+        HIP_TRY(hipHostMalloc((void**)&c->crops_pin, cap, hipHostMallocDefault));
+        c->crops_pin_cap = cap;
     }
+    // The callers' arrays are pageable, and a strided copy out of pageable memory moves row by
+    // row.  The crops are packed into the page-locked mirror by a few host threads, each a
+    // contiguous run of crops, and every run goes to the device as one asynchronous copy as
+    // soon as its thread is done, while the later runs are still being packed.  The mirror is
+    // reused by every call, so copies that an earlier, failed call left in flight are waited for.
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int nthr = (int)(total >> 22);                      // one thread per 4 MiB
+    const int hwc = (int)std::thread::hardware_concurrency();
+    const int lim = hwc >= 16 ? 8 : (hwc >= 4 ? hwc / 2 : 1);
+    if (nthr > lim) nthr = lim;
+    if (nthr > B) nthr = B;
+    if (nthr < 1) nthr = 1;
+    std::vector<int> first(nthr + 1, B);
+    first[0] = 0;
+    for (int t = 1, i = 0; t < nthr; ++t) {
+        while (i < B && (size_t)offsets[i] < total / nthr * t) ++i;
+        first[t] = i;
+    }
+    uint8_t* const pin = c->crops_pin;
+    auto pack = [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) {
+            const size_t h = (size_t)hw[2 * i], row = (size_t)3 * hw[2 * i + 1];
+            uint8_t* dst = pin + offsets[i];
+            if ((size_t)strides[i] == row) { memcpy(dst, crops[i], h * row); continue; }
+            for (size_t y = 0; y < h; ++y) memcpy(dst + y * row, crops[i] + y * (size_t)strides[i], row);
+        }
+    };
+    std::vector<std::thread> workers;
+    for (int t = 1; t < nthr; ++t) workers.emplace_back(pack, first[t], first[t + 1]);
+    pack(first[0], first[1]);
+    hipError_t err = hipSuccess;
+    for (int t = 0; t < nthr; ++t) {
+        if (t > 0) workers[t - 1].join();               // every thread is joined, also after a failed copy
+        if (err != hipSuccess || first[t] >= first[t + 1]) continue;
+        const size_t lo = (size_t)offsets[first[t]];
+        const size_t hi = first[t + 1] < B ? (size_t)offsets[first[t + 1]] : total;
+        err = hipMemcpyAsync(c->crops_dev + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, c->stream);
+    }
+    HIP_TRY(err);
     return FRHOT_OK;
 }
 
@@ -364,6 +408,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
     void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial, c->crops_dev,
                     c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->w6, c->w7, c->b6, c->b7};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->crops_pin) (void)hipHostFree(c->crops_pin);
     for (int l = 0; l < kNumConv; ++l) {
         if (c->act[l]) (void)hipFree(c->act[l]);
         if (c->w[l]) (void)hipFree(c->w[l]);

@@ -26,7 +26,8 @@ def crop(rng: np.random.Generator, h: int, w: int) -> np.ndarray:
     img = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
     gy = np.linspace(-20.0, 20.0, h)[:, None, None]
     img = img + gy + rng.normal(0.0, 3.0, size=(h, w, 3))
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    # fancy indexing leaves the sum in a transposed memory order: hand out plain row-major pixels
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
 
 
 def crops(seed: int, n: int, lo: int = 112, hi: int = 448) -> list:

@@ -121,6 +121,33 @@ def test_embed_batch_invariance(gpu_ctx):
     assert np.array_equal(a[2:3], c)
 
 
+def test_embed_strided_crop_views(gpu_ctx):
+    """The reference hands over `img[y1:y2, x1:x2]` (face_service.py:180-181): a view whose rows are
+    a full image row apart.  Such views give the descriptors of their contiguous copies, also when
+    the batch is large enough for the host staging to be packed by several threads."""
+    from frhot import synth
+    rng = np.random.default_rng(31)
+    big = [synth.crop(rng, 700, 900) for _ in range(4)]
+    views = []
+    for i in range(24):
+        h, w = int(rng.integers(400, 690)), int(rng.integers(500, 890))
+        y, x = int(rng.integers(0, 700 - h + 1)), int(rng.integers(0, 900 - w + 1))
+        views.append(big[i % 4][y:y + h, x:x + w])
+    assert not views[0].flags["C_CONTIGUOUS"]
+    assert sum(v.nbytes for v in views[:16]) > (12 << 20)      # first chunk: three or more packing threads
+    a = gpu_ctx.embed(views, gamma=True)
+    b = gpu_ctx.embed([np.ascontiguousarray(v) for v in views], gamma=True)
+    assert np.array_equal(a, b)
+    # the resized bytes of the last chunk (crops 16..23 at a batch limit of 16) against the oracle
+    from oracle import preprocess as op
+    assert gpu_ctx.max_batch == 16
+    gpu_ctx.embed(views, gamma=True)
+    u8 = gpu_ctx.debug_read(0, 8)
+    for i in (0, 3, 7):
+        want = op.preprocess_u8(np.ascontiguousarray(views[16 + i]), apply_gamma=True, flip=True)
+        assert np.array_equal(u8[i], want), f"view {16 + i}"
+
+
 def test_embed_full_batch(gpu_ctx, weights_f32):
     """The benchmark's batch (256 crops, several tiles per block in every layer, both tile walk
     directions): every descriptor equals, bit for bit, the one the same crop gets in a small batch,
