@@ -3,7 +3,7 @@ face router (app/src/api/routers/face.py:57-72,90-110) behind its X-API-Key chec
 (app/src/api/routes.py:17-28), wired to the GPU engine.
 
 `create_app(ctx)` builds everything in one process: context -> micro-batcher ->
-GalleryService -> DatabaseClient -> FaceService.  The request models repeat the
+GalleryService -> search micro-batcher -> DatabaseClient -> FaceService.  The request models repeat the
 reference's field set (app/src/core/models.py:11-28,43-54).
 """
 from __future__ import annotations
@@ -67,7 +67,7 @@ def build_router(face_service, api_key: str = DEFAULT_API_KEY) -> APIRouter:
 def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002) -> FastAPI:
     """A FastAPI app serving the two routes from one GPU context with a loaded model."""
     from . import legacy
-    from .batcher import EmbedBatcher
+    from .batcher import EmbedBatcher, SearchBatcher
     from .database_client import DatabaseClient
     from .face_service import FaceService
     from .gallery_service import GalleryService
@@ -75,16 +75,19 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
     batcher = EmbedBatcher(ctx, max_delay_s=max_delay_s)
     legacy.install_engine(batcher)
     service = GalleryService(ctx, capacity=capacity)
-    face_service = FaceService(DatabaseClient(service))
+    search_batcher = SearchBatcher(service, max_delay_s=max_delay_s)
+    face_service = FaceService(DatabaseClient(service, search_batcher))
     app = FastAPI(title="frhot recognition path")
     app.include_router(build_router(face_service, api_key))
     app.state.batcher = batcher
+    app.state.search_batcher = search_batcher
     app.state.gallery_service = service
     app.state.face_service = face_service
 
     @app.on_event("shutdown")
     def _shutdown():
         batcher.close()
+        search_batcher.close()
         service.close()
 
     return app

@@ -7,6 +7,7 @@ falsy result the reference returns ([] / False).
 """
 from __future__ import annotations
 
+import asyncio
 import logging
 from typing import Any, Dict, List
 
@@ -14,8 +15,12 @@ logger = logging.getLogger(__name__)
 
 
 class DatabaseClient:
-    def __init__(self, service):
+    def __init__(self, service, search_batcher=None):
+        """`search_batcher`: a frhot.batcher.SearchBatcher over the same service.  With it, searches
+        that are in flight together (the reference allows 10 per process, face_service.py:42) share
+        one gallery scan and the event loop is free while the scan runs."""
         self.service = service
+        self.search_batcher = search_batcher
 
     async def ensure_collection_exists(self, collection_name: str) -> bool:
         """database_client.py:62-96."""
@@ -62,6 +67,9 @@ class DatabaseClient:
                            store_id: str) -> List[Dict[str, Any]]:
         """database_client.py:206-254."""
         try:
+            if self.search_batcher is not None:
+                fut = self.search_batcher.submit(collection_name, vector_embedding, store_id)
+                return self._reshape(*await asyncio.wrap_future(fut))
             return self._reshape(*self.service.search_point(collection_name, vector_embedding, store_id))
         except Exception as e:
             logger.error(f"Error searching points: {e}")

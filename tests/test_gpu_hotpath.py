@@ -471,3 +471,60 @@ def test_gallery_write_f16_restores_bit_for_bit(gpu_ctx, tmp_path):
     assert [svc2.search_point("S9_Employees", list(g[i]), "S9") for i in range(12)] == before
     svc.close()
     svc2.close()
+
+
+def test_api_end_to_end_concurrent_requests(gpu_ctx):
+    """The two routes served from the GPU context (frhot.api.create_app): enrol, then recognise
+    from many requests in flight at once.  The behaviour the reference's manual scripts exercise
+    (test/register.py then test/detect.py: the enrolled picture is recognised as its id and name),
+    plus the grouping of concurrent embeds and searches into shared device calls."""
+    import asyncio
+    import base64
+    import io
+
+    import httpx
+    from PIL import Image
+
+    from frhot import synth
+    from frhot.api import create_app
+
+    def b64(img):
+        buf = io.BytesIO()
+        Image.fromarray(img[:, :, ::-1]).save(buf, format="PNG")
+        return base64.b64encode(buf.getvalue()).decode()
+
+    rng = np.random.default_rng(77)
+    people = [b64(synth.crop(rng, int(rng.integers(120, 300)), int(rng.integers(120, 300)))) for _ in range(12)]
+    app = create_app(gpu_ctx, capacity=256, api_key="k", max_delay_s=0.05)
+    H = {"X-API-Key": "k"}
+
+    async def run():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot") as c:
+            # is_update skips the "face exists" pre-search: descriptors of a randomly initialised
+            # network are all close to each other, so a second person would be answered 409
+            for i, img in enumerate(people):
+                r = await c.post("/create_face_img_base64", headers=H, json={
+                    "img_base64": img, "id": str(100 + i), "name": f"P{i}", "role": "1", "store_id": "S", "is_update": True})
+                assert r.status_code == 201, r.text
+            r = await c.post("/create_face_img_base64", headers=H, json={
+                "img_base64": people[0], "id": "999", "name": "Dup", "role": "1", "store_id": "S"})
+            assert r.status_code == 409
+            b0, s0 = app.state.batcher.batches, app.state.search_batcher.batches
+            rs = await asyncio.gather(*[c.post("/face_recog_img_base64", headers=H, json={
+                "img_base64": img, "role": "1", "store_id": "S"}) for img in people])
+            for i, r in enumerate(rs):
+                assert r.status_code == 200 and r.json() == {"status": 1, "id": str(100 + i), "name": f"P{i}"}, r.text
+            assert app.state.batcher.batches - b0 < len(people)            # crops shared device calls
+            assert app.state.search_batcher.batches - s0 < len(people)     # and so did the searches
+            r = await c.post("/face_recog_img_base64", headers=H, json={"img_base64": people[0], "role": "0", "store_id": "S"})
+            assert r.status_code == 404                                    # nothing enrolled among the customers
+            r = await c.post("/face_recog_img_base64", json={"img_base64": people[0], "role": "1", "store_id": "S"})
+            assert r.status_code == 403
+    try:
+        asyncio.run(run())
+    finally:
+        app.state.batcher.close()
+        app.state.search_batcher.close()
+        app.state.gallery_service.close()
+        from frhot import legacy
+        legacy.install_engine(None)

@@ -302,3 +302,42 @@ def test_micro_batcher_groups_concurrent_callers():
     for i in range(20):
         assert out[i][0] == i + (100 if i % 2 else 0)
     assert sum(ctx.sizes) == 20 and max(ctx.sizes) <= 8 and len(ctx.sizes) < 20
+
+
+def test_search_batcher_groups_concurrent_searches():
+    """Searches in flight together share one scan; every caller gets the answer the unbatched
+    service gives, including the validation failures and the empty-collection answer."""
+    from frhot.batcher import SearchBatcher
+    from frhot.database_client import DatabaseClient
+    svc = _service(64, 256)
+    rng = np.random.default_rng(4)
+    vecs = rng.standard_normal((40, 64)).astype(np.float32)
+    for col in ("A_Employees", "A_Customers", "B_Employees"):
+        svc.create_collection(col)
+    for i in range(40):
+        col = ("A_Employees", "A_Customers")[i % 2]
+        assert svc.insert_point(col, list(vecs[i]), str(i), f"n{i}", "A")[0] == 201
+    calls = []
+    real_search = svc.gallery.search
+    svc.gallery.search = lambda q, qkeys=None, k=5: (calls.append(len(q)), real_search(q, qkeys, k))[1]
+    reqs = [(("A_Employees", "A_Customers")[i % 2], list(vecs[i]), "A") for i in range(40)]
+    reqs += [("B_Employees", list(vecs[0]), "B"), ("missing", list(vecs[0]), "A"), ("A_Employees", [0.0] * 3, "A")]
+    want = [svc.search_point(*r) for r in reqs]
+    assert want[0][1]["message"] == "Point found" and want[0][1]["data"][0][1]["id"] == "0"
+    assert want[40] == (200, {"message": "Point not found", "data": []}) and want[41][0] == 404 and want[42][0] == 404
+    n_unbatched = len(calls)
+    calls.clear()
+    sb = SearchBatcher(svc, max_batch=64, max_delay_s=0.05)
+    cli = DatabaseClient(svc, sb)
+
+    async def run():
+        return await asyncio.gather(*[cli.search_point(*r) for r in reqs])
+    got = asyncio.run(run())
+    sb.close()
+    ref = [DatabaseClient._reshape(*w) for w in want]
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):          # the stand-in's BLAS rounds a batch differently in the last bit
+        assert [(x["id"], x["payload"]) for x in g] == [(x["id"], x["payload"]) for x in r]
+        assert np.allclose([x["score"] for x in g], [x["score"] for x in r], atol=1e-6)
+    assert sum(calls) == n_unbatched and len(calls) < 5      # 40 real scans' worth of queries in a few calls
+    assert sb.items == len(reqs) and sb.batches < 5
