@@ -164,6 +164,16 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Free a device buffer and forget it in one step, so that a failure further on never leaves a
+// freed pointer behind.
+template <class T>
+hipError_t free_null(T*& p) {
+    if (!p) return hipSuccess;
+    T* q = p;
+    p = nullptr;
+    return hipFree(q);
+}
+
 int upload(void** dst, const void* src, size_t n) {
     HIP_TRY(hipMalloc(dst, n));
     HIP_TRY(hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
@@ -221,16 +231,16 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     }
     if (total > c->crops_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->crops_dev) HIP_TRY(hipFree(c->crops_dev));
-        c->crops_dev = nullptr; c->crops_cap = 0;
+        c->crops_cap = 0;
+        HIP_TRY(free_null(c->crops_dev));
         const size_t cap = total + total / 4 + 4096;
         HIP_TRY(hipMalloc((void**)&c->crops_dev, cap));
         c->crops_cap = cap;
     }
     if (total > c->crops_pin_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->crops_pin) HIP_TRY(hipHostFree(c->crops_pin));
-        c->crops_pin = nullptr; c->crops_pin_cap = 0;
+        c->crops_pin_cap = 0;
+        if (uint8_t* old = c->crops_pin) { c->crops_pin = nullptr; HIP_TRY(hipHostFree(old)); }
         const size_t cap = total + total / 4 + 4096;
         HIP_TRY(hipHostMalloc((void**)&c->crops_pin, cap, hipHostMallocDefault));
         c->crops_pin_cap = cap;
@@ -295,9 +305,9 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
     const size_t need = (size_t)scan_max_blocks() * Bq * kl;
     if (need > g->part_cap) {
         HIP_TRY(hipStreamSynchronize(s));
-        if (g->part_s) HIP_TRY(hipFree(g->part_s));
-        if (g->part_r) HIP_TRY(hipFree(g->part_r));
-        g->part_s = nullptr; g->part_r = nullptr; g->part_cap = 0;
+        g->part_cap = 0;
+        HIP_TRY(free_null(g->part_s));
+        HIP_TRY(free_null(g->part_r));
         HIP_TRY(hipMalloc((void**)&g->part_s, need * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&g->part_r, need * sizeof(int64_t)));
         g->part_cap = need;
@@ -586,10 +596,10 @@ int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* key
     DeviceGuard dg(c->device);
     if (n > g->up_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (g->up_vecs) HIP_TRY(hipFree(g->up_vecs));
-        if (g->up_keys) HIP_TRY(hipFree(g->up_keys));
-        if (g->up_rows) HIP_TRY(hipFree(g->up_rows));
-        g->up_vecs = nullptr; g->up_keys = nullptr; g->up_rows = nullptr; g->up_cap = 0;
+        g->up_cap = 0;
+        HIP_TRY(free_null(g->up_vecs));
+        HIP_TRY(free_null(g->up_keys));
+        HIP_TRY(free_null(g->up_rows));
         const int cap = n + n / 2 + 16;
         HIP_TRY(hipMalloc((void**)&g->up_vecs, (size_t)cap * g->D * 4));
         HIP_TRY(hipMalloc((void**)&g->up_keys, (size_t)cap * 4));

@@ -19,7 +19,7 @@ for k,c in agg.items():
     gui=row.get("GRBM_GUI_ACTIVE",0)
     clk=gui/8/dur if dur else 0   # GHz (cycles per ns)
     print(k[:70])
-    print("   dur_us %.1f clk_GHz %.2f mfma_busy/(gui/8*... ) %.3f  lds_active_frac %.3f bank_conf_frac %.3f wait_any/wave %.3f wait_inst_any/wave %.3f wait_lds/wave %.3f" % (
+    print("   dur_us %.1f clk_GHz %.2f mfma_busy_frac %.3f  lds_active_frac %.3f bank_conf_frac %.3f wait_any/wave %.3f wait_inst_any/wave %.3f wait_lds/wave %.3f" % (
         dur/1e3, clk,
         row["SQ_VALU_MFMA_BUSY_CYCLES"]/ (gui/8*256*4) if gui else 0,
         row["SQ_LDS_IDX_ACTIVE"]/(gui/8*256) if gui else 0,
