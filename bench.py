@@ -119,11 +119,15 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none is visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if os.environ.get("FRHOT_BENCH_WATCHDOG_S"):      # diagnosis: say where a hung run stands, then end it
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FRHOT_BENCH_WATCHDOG_S"]), exit=True)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from frhot import synth
     from frhot.dist import ShardedSearch, shard_rows
@@ -134,7 +138,7 @@ def main():
     row_base, rows_local = shard_rows(args.gallery_rows, P, rank)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = Context(device=local_rank, max_batch=B, stream=stream.cuda_stream)
+        ctx = Context(device=dev_index, max_batch=B, stream=stream.cuda_stream)
         ctx.load_model(pack_blob(synthetic_weights(seed=args.seed & 0xFFFF)), input_scale=1.0 / 16.0)
         images = synth.crops(seed=args.seed + 3 + rank, n=B, lo=112, hi=448)
         buf, offsets, hw, strides = synth.pack_crops(images)
