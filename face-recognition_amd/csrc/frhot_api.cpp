@@ -746,7 +746,8 @@ int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq,
 int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_dev, int P, int Bq, int k,
                          void* out_scores_dev, void* out_rows_dev) {
     if (!c || !scores_dev || !rows_dev || !out_scores_dev || !out_rows_dev) return fail(FRHOT_EINVAL, "null argument");
-    if (P <= 0 || Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "P %d / Bq %d / k %d out of range", P, Bq, k);
+    if (P <= 0 || P > 256 || Bq <= 0 || k <= 0 || k > 16)
+        return fail(FRHOT_EINVAL, "P %d / Bq %d / k %d out of range (P <= 256, k <= 16)", P, Bq, k);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
     HIP_TRY(launch_topk_final((const float*)scores_dev, (const int64_t*)rows_dev, P, k, Bq, k, 0,

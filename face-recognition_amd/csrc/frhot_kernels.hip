@@ -536,6 +536,27 @@ FR_DEV float lanes4_min(float v) {
     return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// float -> unsigned with the same order (and back); key 0 is below every float's key
+FR_DEV unsigned ordered_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+FR_DEV float ordered_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Unsigned max over aligned groups of N = 8 or 16 adjacent lanes, result in every lane of the
+// group: a butterfly of DPP lane permutations (pairs, quads, mirrored halves, mirrored row).
+template <int N>
+FR_DEV unsigned group_umax(unsigned v) {
+#define FR_DPP_MAX(ctrl)                                                                                  \
+    { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false); v = v > o ? v : o; }
+    FR_DPP_MAX(0xB1)        // quad_perm [1,0,3,2]
+    FR_DPP_MAX(0x4E)        // quad_perm [2,3,0,1]
+    FR_DPP_MAX(0x141)       // row_half_mirror: lane i <- lane 7 - i of its half row
+    if (N == 16) FR_DPP_MAX(0x140)      // row_mirror: lane i <- lane 15 - i of its row
+#undef FR_DPP_MAX
+    return v;
+}
+
 template <int K>
 struct TopK {
     float s[K];
@@ -1593,7 +1614,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         }
     }
 
-    // merge the WX*4 lists of each query through LDS, one thread per query
+    // merge the WX*4 lists of each query through LDS
     constexpr int NL = WX * 4;
     __syncthreads();
     float* ls = (float*)smem;                       // [RY][NL][K]
@@ -1608,82 +1629,121 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         }
     }
     __syncthreads();
-    if (tid < RY && q0 + tid < Bq) {
-        TopK<K> m;
-        m.init();
-        for (int c = 0; c < NL * K; ++c) {
-            const float v = ls[tid * NL * K + c];
-            const int rr = lr[tid * NL * K + c];
-            if (rr >= 0 && m.beats_tail(v, rr)) m.template push<true>(v, rr);
-        }
-        const size_t o = ((size_t)gb * Bq + q0 + tid) * K;
+    // Each query's NL lists are sorted (score descending, row ascending inside equal scores), so
+    // their best K come out of a K-round merge of the list heads: NL adjacent lanes per query,
+    // one per list; a round finds the group's best head (max score, then min row) by DPP
+    // exchanges inside the group and the lane that holds it moves on to its list's next entry.
+    constexpr int QPP = 512 / NL;                   // queries per pass
+    static_assert(RY % QPP == 0 && (NL == 8 || NL == 16), "merge groups");
+    const int sub = tid % NL, qslot = tid / NL;
+#pragma unroll 1
+    for (int qb = 0; qb < RY; qb += QPP) {
+        const int ql = qb + qslot;
+        const float* const hs = ls + (ql * NL + sub) * K;
+        const int* const hrw = lr + (ql * NL + sub) * K;
+        int pos = 0;
+        int r = hrw[0];
+        unsigned hk = r >= 0 ? ordered_key(hs[0]) : 0u;
+        unsigned hr = r >= 0 ? (unsigned)r : 0xffffffffu;
+        const size_t o = ((size_t)gb * Bq + q0 + ql) * K;
+        const bool writer = sub == 0 && q0 + ql < Bq;
 #pragma unroll
-        for (int i = 0; i < K; ++i) { part_s[o + i] = m.s[i]; part_r[o + i] = m.r[i]; }
+        for (int i = 0; i < K; ++i) {
+            const unsigned kmax = group_umax<NL>(hk);
+            const bool c1 = hk == kmax;
+            const unsigned rmin = ~group_umax<NL>(~(c1 ? hr : 0xffffffffu));
+            if (writer) {
+                part_s[o + i] = kmax ? ordered_value(kmax) : -INFINITY;
+                part_r[o + i] = kmax ? (long long)rmin : -1;
+            }
+            if (c1 && hr == rmin && kmax != 0u) {
+                ++pos;
+                r = pos < K ? hrw[pos < K ? pos : 0] : -1;
+                const float v = hs[pos < K ? pos : 0];
+                hk = r >= 0 ? ordered_key(v) : 0u;
+                hr = r >= 0 ? (unsigned)r : 0xffffffffu;
+            }
+        }
     }
 }
 
-// One wave per query: select the best kout of nlists*kin candidates.
+// Wave-wide unsigned max / min through DPP row shifts and row broadcasts: no LDS traffic, the
+// result is uniform.  Lanes without a source keep `identity`.
+FR_DEV unsigned wave_umax(unsigned v) {
+#define FR_DPP_STEP(ctrl, rows)                                                                          \
+    { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false); v = v > o ? v : o; }
+    FR_DPP_STEP(0x111, 0xf) FR_DPP_STEP(0x112, 0xf) FR_DPP_STEP(0x114, 0xf) FR_DPP_STEP(0x118, 0xf)   // row_shr 1,2,4,8
+    FR_DPP_STEP(0x142, 0xa) FR_DPP_STEP(0x143, 0xc)                                                   // row_bcast 15, 31
+#undef FR_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+FR_DEV unsigned wave_umin(unsigned v) { return ~wave_umax(~v); }
+
+
+// One wave per query: the best kout of nlists candidate lists of kin entries each.  Every list
+// arrives SORTED (score descending, row ascending inside equal scores; unused tail entries have
+// row -1): the scan's per-block lists and a shard's final lists both are.  So no candidate is
+// ever inserted anywhere: lane l owns lists l, l+64, l+128, l+192, keeps the head of each, and a
+// round picks the best head of the wave (max score, then min row, by DPP reductions) and advances
+// that one list.  The lists are staged once in LDS, each lane reading back only what it wrote, as
+// per-lane scratch that can be indexed by a position.  Tie order = ascending row.
 template <int K>
 __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict__ cs,
                                                         const long long* __restrict__ cr, int nlists, int kin,
                                                         int Bq, int kout, long long row_base,
                                                         float* __restrict__ out_s, long long* __restrict__ out_r) {
+    constexpr int NL = 4;                         // lists per lane: nlists <= 256 (checked at launch)
+    __shared__ float ls[K * 64 * NL];
+    __shared__ long long lr[K * 64 * NL];
     const int qi = blockIdx.x, lane = threadIdx.x;
-    // rows are compared as 64-bit values here: keep them beside the int list as (hi, lo)
-    float s[K]; long long r[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) { s[i] = -INFINITY; r[i] = -1; }
-    const int total = nlists * kin;
-    // twenty candidates per lane are fetched before any is examined: the kernel is a handful of
-    // waves, so its time is the number of dependent memory round trips
-    constexpr int NB = 20;
-    for (int c0 = lane; c0 < total; c0 += 64 * NB) {
-        float bv[NB]; long long br[NB];
+    for (int t = 0; t < NL; ++t) {
+        const int p = lane + 64 * t;
+        const size_t a = ((size_t)(p < nlists ? p : 0) * Bq + qi) * kin;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int c = c0 + 64 * t;
-            const int cc = c < total ? c : lane;
-            const int p = cc / kin, j = cc % kin;
-            const size_t a = ((size_t)p * Bq + qi) * kin + j;
-            bv[t] = cs[a];
-            br[t] = c < total ? cr[a] : -1;
-        }
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const float v = bv[t];
-            const long long rr = br[t];
-            if (rr < 0) continue;
-            const bool beats = v > s[K - 1] || (v == s[K - 1] && (r[K - 1] < 0 || rr < r[K - 1]));
-            if (!beats) continue;
-            s[K - 1] = v; r[K - 1] = rr;
-#pragma unroll
-            for (int i = K - 1; i > 0; --i) {
-                const bool sw = s[i] > s[i - 1] || (s[i] == s[i - 1] && (r[i - 1] < 0 || r[i] < r[i - 1]));
-                const float ts = s[i - 1]; const long long tr = r[i - 1];
-                s[i - 1] = sw ? s[i] : ts; r[i - 1] = sw ? r[i] : tr;
-                s[i] = sw ? ts : s[i];     r[i] = sw ? tr : r[i];
-            }
+        for (int j = 0; j < K; ++j) {
+            const bool have = p < nlists && j < kin;
+            ls[(j * NL + t) * 64 + lane] = have ? cs[a + j] : -INFINITY;
+            lr[(j * NL + t) * 64 + lane] = have ? cr[a + j] : -1;
         }
     }
+    // heads: (ordered score key, row); an exhausted or empty list has key 0 and the largest row
+    constexpr long long NOROW = 0x7fffffffffffffffLL;
+    unsigned hk[NL]; long long hr[NL]; int pos[NL];
+    auto load_head = [&](int t) __attribute__((always_inline)) {
+        const long long r = pos[t] < K ? lr[(pos[t] * NL + t) * 64 + lane] : -1;
+        const float v = pos[t] < K ? ls[(pos[t] * NL + t) * 64 + lane] : -INFINITY;
+        hk[t] = r >= 0 ? ordered_key(v) : 0u;
+        hr[t] = r >= 0 ? r : NOROW;
+    };
+#pragma unroll
+    for (int t = 0; t < NL; ++t) { pos[t] = 0; load_head(t); }
     for (int o = 0; o < kout; ++o) {
-        float bs = s[0]; long long br = r[0]; int bl = lane;
+        unsigned bk = hk[0]; long long br = hr[0]; int bt = 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const float os = __shfl_xor(bs, d);
-            const long long orr = __shfl_xor(br, d);
-            const int ol = __shfl_xor(bl, d);
-            const bool take = (orr >= 0) && (br < 0 || os > bs || (os == bs && (orr < br || (orr == br && ol < bl))));
-            if (take) { bs = os; br = orr; bl = ol; }
+        for (int t = 1; t < NL; ++t) {
+            const bool take = hk[t] > bk || (hk[t] == bk && hr[t] < br);
+            bk = take ? hk[t] : bk; br = take ? hr[t] : br; bt = take ? t : bt;
         }
+        const unsigned kmax = wave_umax(bk);
+        const bool c1 = bk == kmax;
+        const unsigned hmin = wave_umin(c1 ? (unsigned)((unsigned long long)br >> 32) : 0xffffffffu);
+        const bool c2 = c1 && (unsigned)((unsigned long long)br >> 32) == hmin;
+        const unsigned lmin = wave_umin(c2 ? (unsigned)(unsigned long long)br : 0xffffffffu);
+        const bool c3 = c2 && (unsigned)(unsigned long long)br == lmin;
+        const long long rwin = (long long)(((unsigned long long)hmin << 32) | lmin);
+        const bool found = kmax != 0u;
         if (lane == 0) {
-            out_s[(size_t)qi * kout + o] = br >= 0 ? bs : -INFINITY;
-            out_r[(size_t)qi * kout + o] = br >= 0 ? br + row_base : -1;
+            out_s[(size_t)qi * kout + o] = found ? ordered_value(kmax) : -INFINITY;
+            out_r[(size_t)qi * kout + o] = found ? rwin + row_base : -1;
         }
-        if (lane == bl && br >= 0) {
+        if (!found) continue;                                    // uniform: every list is exhausted
+        // one lane advances the list that supplied the winner (the lowest lane, should two hold it)
+        const unsigned long long m = __ballot(c3);
+        const bool me = c3 && lane == (int)__builtin_ctzll(m);
 #pragma unroll
-            for (int i = 0; i < K - 1; ++i) { s[i] = s[i + 1]; r[i] = r[i + 1]; }
-            s[K - 1] = -INFINITY; r[K - 1] = -1;
-        }
+        for (int t = 0; t < NL; ++t)
+            if (me && bt == t) { ++pos[t]; load_head(t); }
     }
 }
 
@@ -1941,7 +2001,8 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
 
 hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
                              int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s) {
-    if (nlists <= 0 || kin <= 0 || kin > 16 || Bq <= 0 || kout <= 0 || kout > kin || !cs || !cr || !out_s || !out_r)
+    if (nlists <= 0 || nlists > 256 || kin <= 0 || kin > 16 || Bq <= 0 || kout <= 0 || kout > kin || !cs || !cr ||
+        !out_s || !out_r)
         return hipErrorInvalidValue;
     const int kl = scan_klist(kin);
     if (kl == 5)

@@ -183,6 +183,8 @@ int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qke
 /*
  * Merge P per-shard answers (the all-gathered outputs of frhot_search_dev laid
  * out [P,Bq,k]) into the global top-k [Bq,k].  All pointers are device memory.
+ * P <= 256; every per-shard list must be in the order frhot_search_dev writes
+ * (score descending, row ascending inside equal scores, unused tail rows -1).
  * Replaces: nothing in the reference (one Qdrant node); it is the reduce step
  * of the row-sharded scan.
  */

@@ -182,8 +182,14 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
         [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, &nblk, s)); }, 2, 10, s);
     const double bytes = (double)N * D * 2 + (use_keys ? (double)N * 4 : 0.0) + (double)Bq * D * 2;
     const double fl = 2.0 * Bq * (double)N * D;
-    printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d\n",
-           N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk);
+    float* os;
+    int64_t* orr;
+    CK(hipMalloc((void**)&os, (size_t)Bq * k * 4));
+    CK(hipMalloc((void**)&orr, (size_t)Bq * k * 8));
+    const float ms_final = time_ms([&] { CK(launch_topk_final(ps, pr, nblk, kl, Bq, k, 0, os, orr, s)); }, 2, 10, s);
+    printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d  final merge %.3f ms\n",
+           N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk, ms_final);
+    CK(hipFree(os)); CK(hipFree(orr));
     CK(hipFree(g)); CK(hipFree(gk)); CK(hipFree(q)); CK(hipFree(ps)); CK(hipFree(pr));
     if (qk) CK(hipFree(qk));
 }
