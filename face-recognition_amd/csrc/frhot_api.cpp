@@ -132,6 +132,7 @@ struct frhot_gallery {
     void* rows = nullptr;
     int32_t* keys = nullptr;
     float* part_s = nullptr; int64_t* part_r = nullptr; size_t part_cap = 0;
+    unsigned* qbound = nullptr; size_t qbound_cap = 0;   // cross-block score bounds of the scan
     // host-call staging
     float* up_vecs = nullptr; int32_t* up_keys = nullptr; int64_t* up_rows = nullptr; int up_cap = 0;
     void* q16 = nullptr; float* q32 = nullptr; int32_t* qk = nullptr; float* out_s = nullptr; int64_t* out_r = nullptr;
@@ -312,11 +313,19 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
         HIP_TRY(hipMalloc((void**)&g->part_r, need * sizeof(int64_t)));
         g->part_cap = need;
     }
+    if (scan_bound_bytes(Bq) > g->qbound_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->qbound_cap = 0;
+        HIP_TRY(free_null(g->qbound));
+        const size_t cap = scan_bound_bytes(Bq + Bq / 2);
+        HIP_TRY(hipMalloc((void**)&g->qbound, cap));
+        g->qbound_cap = cap;
+    }
     int nblk = 0;
     if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
     const int use_keys = (qkeys_dev != nullptr || !g->dense) ? 1 : 0;
     HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, use_keys, Bq, k, g->part_s, g->part_r,
-                             &nblk, s));
+                             g->qbound, &nblk, s));
     if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_topk_final(g->part_s, g->part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
     if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
@@ -573,7 +582,7 @@ int frhot_gallery_destroy(frhot_gallery* g) {
     std::lock_guard<std::mutex> lk(g->ctx->mu);
     DeviceGuard dg(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    void* ptrs[] = {g->rows, g->keys, g->part_s, g->part_r, g->up_vecs, g->up_keys, g->up_rows,
+    void* ptrs[] = {g->rows, g->keys, g->part_s, g->part_r, g->qbound, g->up_vecs, g->up_keys, g->up_rows,
                     g->q16, g->q32, g->qk, g->out_s, g->out_r};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete g;

@@ -60,9 +60,11 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* q_f16, int Bq, int D, hi
 // Scan: per-block partial top-k lists into part_s/part_r ([nblk][Bq][k]); returns nblk via *nblk_out.
 int scan_max_blocks();
 // g_f16 / g_keys must be allocated in whole tiles of 256 rows (reads run to the tile end).
+// qbound: scan_bound_bytes(Bq) bytes of device scratch (cross-block score bounds), or null.
+size_t scan_bound_bytes(int Bq);
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
-                            float* part_s, int64_t* part_r, int* nblk_out, hipStream_t s);
+                            float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s);
 // Length of the per-block candidate lists the scan writes for a request of k (5, 10 or 16).
 int scan_list_len(int k);
 // Final selection over nlists lists of kin (layout [nlists][Bq][kin]) -> best kout per query.

@@ -1333,7 +1333,8 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                                                            const int32_t* __restrict__ gkeys, long nrows, int D,
                                                            const half_t* __restrict__ q,
                                                            const int32_t* __restrict__ qkeys, int Bq, int nb,
-                                                           float* __restrict__ part_s, long long* __restrict__ part_r) {
+                                                           float* __restrict__ part_s, long long* __restrict__ part_r,
+                                                           unsigned* __restrict__ qbound) {
     static_assert(WX * WY == 8 && RY % 64 == 0, "shape");
     constexpr int TX = 256 / WX, TY = RY / WY, NX = TX / 16, NY = TY / 16;
     constexpr int XB = 256 * 128, YB = RY * 128;
@@ -1430,6 +1431,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         half8 fx[NXH], fy[NY];
         int xslot = 0, yslot = 0, ks = 0;
         long tile = gb;
+        unsigned tdone = 0;             // tiles this block has finished
         for (long s = 0; s < S; ++s) {
             const char* const xbuf = xs + xslot * XB;
             const char* const ybuf = ys + yslot * YB;
@@ -1596,6 +1598,58 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                                 m2 = fmaxf(m2, v[x][j]);
                             }
                         m = want ? m2 : -INFINITY;     // a lane with nothing to insert is done with this tile
+                    }
+                }
+                // Cross-block bound.  A lane's list sees 1/(4*WX*nb) of the rows, so its own K-th best
+                // is a weak filter and, without more, nearly every tile finds some lane with a score
+                // to insert.  qbound holds K slots per query; every wave of every block belongs to
+                // one slot (wave number mod K) and raises it to the best score its lanes hold for the query.
+                // The slots' minimum t is then a lower bound on the query's K-th best score over the
+                // WHOLE gallery seen so far: K different lists each hold a row scoring >= t.  Scores
+                // below t can never reach the answer (scores equal to t can: the order among equal
+                // scores is by row), so list entries below t become placeholders (row -1) at
+                // the largest value below t, which makes the ordinary "beats the tail" test apply the
+                // bound.  Stale or lost slot updates only weaken the bound.  Done after tiles 1, 2,
+                // 4, 8, 16, ...: the wait for the reads costs about one memory round trip, and the
+                // bound moves little once a block has seen a few thousand rows.
+                ++tdone;
+                if (qbound != nullptr && (tdone & (tdone - 1)) == 0) {
+                    unsigned bk[NY], mine[NY];
+                    // a "list" here is the union of the four lanes' lists of one query in one wave
+                    const unsigned list = (unsigned)gb * WX + wx;
+                    const int myslot = (int)(list % K);
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        const int qq = q0 + wy * TY + y * 16 + l15;          // qbound has a row for every query of the tile
+                        const unsigned* const sl = qbound + (size_t)qq * K;
+                        unsigned m = 0xffffffffu, cur = 0u;
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const unsigned v = __hip_atomic_load(sl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            m = v < m ? v : m;
+                            cur = j == myslot ? v : cur;
+                        }
+                        bk[y] = m; mine[y] = cur;
+                    }
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        // raise the list's slot only when that changes it: all lists of a slot address
+                        // one word, and atomics on one word are served one after the other
+                        const int qq = q0 + wy * TY + y * 16 + l15;
+                        // (a lane without a row yet holds -inf: below every real score's key)
+                        const unsigned hk = ordered_key(lanes4_max(top[y].s[0]));
+                        if (g0 == 0 && hk > ordered_key(-INFINITY) && hk > mine[y])
+                            (void)__hip_atomic_fetch_max(qbound + (size_t)qq * K + myslot, hk, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                        if (bk[y] > 1u) {                       // 0: some slot is still empty
+                            const float below = ordered_value(bk[y] - 1u);
+#pragma unroll
+                            for (int i = 0; i < K; ++i) {
+                                const bool drop = !(top[y].s[i] > below);
+                                top[y].r[i] = drop ? -1 : top[y].r[i];
+                                top[y].s[i] = drop ? below : top[y].s[i];
+                            }
+                        }
                     }
                 }
                 ks = 0; tile += nb;
@@ -1945,7 +1999,8 @@ static int scan_query_tile(int Bq, int kl) {
 
 template <int K, int RY, int WX, int WY, bool USE_KEYS>
 static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
-                            int Bq, int nb, float* part_s, int64_t* part_r, hipStream_t s, bool attr_only) {
+                            int Bq, int nb, float* part_s, int64_t* part_r, unsigned* qbound, hipStream_t s,
+                            bool attr_only) {
     constexpr int xs = RY <= 64 ? 4 : 3, ys = RY <= 128 ? 3 : 2;
     constexpr int ring = xs * 256 * 128 + ys * RY * 128;
     constexpr int merge = RY * WX * 4 * K * 8;
@@ -1955,18 +2010,18 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,
-                       (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r);
+                       (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r, qbound);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
 
 static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const int32_t* gk, long nrows, int D,
                                 const void* q, const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr,
-                                hipStream_t s, bool attr) {
+                                unsigned* qb, hipStream_t s, bool attr) {
 #define FR_SCAN(K, RY, WX, WY)                                                                              \
     if (kl == K && ry == RY)                                                                                  \
-        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, s, attr)      \
-                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, s, attr);
+        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr)  \
+                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr);
     FR_SCAN(5, 64, 4, 2)
     FR_SCAN(5, 128, 4, 2)
     FR_SCAN(5, 256, 2, 4)
@@ -1979,9 +2034,13 @@ static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const 
 
 // `use_keys`: apply the per-row key test (needed when query keys are given or the gallery
 // may hold dead rows).  The gallery buffers must be padded to a multiple of 256 rows.
+size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 16 * sizeof(unsigned); }
+
+// `qbound`: scan_bound_bytes(Bq) bytes of device scratch for the cross-block score bounds (cleared
+// here, on the stream, before the kernel), or null to scan without them.
 hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
                             const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
-                            int* nblk_out, hipStream_t s) {
+                            unsigned* qbound, int* nblk_out, hipStream_t s) {
     if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q ||
         !part_s || !part_r || !nblk_out || (use_keys && !gk))
         return hipErrorInvalidValue;
@@ -1996,7 +2055,14 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
     const long nt8 = (ntiles + 7) & ~7L;
     if (nb > nt8) nb = (int)nt8;
     *nblk_out = nb;
-    return scan_dispatch(kl, ry, use_keys != 0, g, gk, (long)nrows, D, q, qkeys, Bq, nb, part_s, part_r, s, false);
+    // the bounds pay once a block walks enough tiles to amortise their reads (and the clearing launch)
+    if (ntiles / nb < 32) qbound = nullptr;
+    if (qbound) {
+        hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq), s);
+        if (e != hipSuccess) return e;
+    }
+    return scan_dispatch(kl, ry, use_keys != 0, g, gk, (long)nrows, D, q, qkeys, Bq, nb, part_s, part_r, qbound, s,
+                         false);
 }
 
 hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
@@ -2035,7 +2101,7 @@ hipError_t kernels_init() {
     for (const auto& c : combos)
         for (int keys = 0; keys < 2; ++keys) {
             e = scan_dispatch(c[0], c[1], keys != 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr,
-                              nullptr, true);
+                              nullptr, nullptr, true);
             if (e != hipSuccess) return e;
         }
     return hipSuccess;

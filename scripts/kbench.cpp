@@ -177,9 +177,11 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
     int64_t* pr;
     CK(hipMalloc((void**)&ps, (size_t)scan_max_blocks() * Bq * kl * 4));
     CK(hipMalloc((void**)&pr, (size_t)scan_max_blocks() * Bq * kl * 8));
+    unsigned* qb = nullptr;
+    if (!getenv("KBENCH_NO_BOUND")) CK(hipMalloc((void**)&qb, scan_bound_bytes(Bq)));
     int nblk = 0;
     const float ms = time_ms(
-        [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, &nblk, s)); }, 2, 10, s);
+        [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, qb, &nblk, s)); }, 2, 10, s);
     const double bytes = (double)N * D * 2 + (use_keys ? (double)N * 4 : 0.0) + (double)Bq * D * 2;
     const double fl = 2.0 * Bq * (double)N * D;
     float* os;
@@ -190,6 +192,7 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
     printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d  final merge %.3f ms\n",
            N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk, ms_final);
     CK(hipFree(os)); CK(hipFree(orr));
+    if (qb) CK(hipFree(qb));
     CK(hipFree(g)); CK(hipFree(gk)); CK(hipFree(q)); CK(hipFree(ps)); CK(hipFree(pr));
     if (qk) CK(hipFree(qk));
 }

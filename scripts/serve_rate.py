@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Developer tool: requests/s through the two FastAPI routes of frhot.api.create_app, in process
+(httpx ASGI transport, no sockets), with `conc` recognise requests in flight at a time.
+
+It measures the Python host stack the reference keeps (base64 + image decode, gamma LUT, the
+list-of-floats embedding, the vote) on top of the GPU path; the micro-batchers turn the
+requests that wait together into shared device calls.
+Usage: python scripts/serve_rate.py [conc] [requests] [enrolled]
+"""
+import asyncio
+import base64
+import io
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "face-recognition_amd"))
+
+import httpx  # noqa: E402
+import numpy as np  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from frhot import synth  # noqa: E402
+from frhot.api import create_app  # noqa: E402
+from frhot.engine import Context  # noqa: E402
+from frhot.weights import pack_blob, synthetic_weights  # noqa: E402
+
+
+def b64_jpeg(img):
+    buf = io.BytesIO()
+    Image.fromarray(img[:, :, ::-1]).save(buf, format="JPEG", quality=90)
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+async def main():
+    conc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    total = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    enrolled = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    ctx = Context(device=0, max_batch=256)
+    ctx.load_model(pack_blob(synthetic_weights(seed=0xFACE)), input_scale=1.0 / 16.0)
+    app = create_app(ctx, capacity=1 << 16, api_key="k", max_delay_s=0.004)
+    rng = np.random.default_rng(5)
+    faces = [b64_jpeg(synth.crop(rng, int(rng.integers(160, 400)), int(rng.integers(160, 400)))) for _ in range(enrolled)]
+    H = {"X-API-Key": "k"}
+    async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot", timeout=120) as c:
+        for i, img in enumerate(faces):
+            r = await c.post("/create_face_img_base64", headers=H, json={
+                "img_base64": img, "id": str(i), "name": f"P{i}", "role": "1", "store_id": "S", "is_update": True})
+            assert r.status_code == 201, r.text
+        sem = asyncio.Semaphore(conc)
+        ok = 0
+
+        async def one(i):
+            nonlocal ok
+            async with sem:
+                r = await c.post("/face_recog_img_base64", headers=H, json={
+                    "img_base64": faces[i % enrolled], "role": "1", "store_id": "S"})
+                ok += r.status_code == 200 and r.json().get("id") == str(i % enrolled)
+        await asyncio.gather(*[one(i) for i in range(min(total, 2 * conc))])      # warm-up
+        ok = 0
+        b0, s0 = app.state.batcher.batches, app.state.search_batcher.batches
+        t0 = time.perf_counter()
+        await asyncio.gather(*[one(i) for i in range(total)])
+        dt = time.perf_counter() - t0
+        nb, ns = app.state.batcher.batches - b0, app.state.search_batcher.batches - s0
+    print(f"serve: {total} recognise requests, {conc} in flight: {total / dt:.0f} requests/s, {dt / total * 1e3:.2f} ms each; "
+          f"{ok} answered with the enrolled id; {nb} embed calls ({total / max(nb, 1):.1f} crops each), "
+          f"{ns} scans ({total / max(ns, 1):.1f} queries each)")
+    app.state.batcher.close()
+    app.state.search_batcher.close()
+    app.state.gallery_service.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    asyncio.run(main())

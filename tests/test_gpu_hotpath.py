@@ -219,11 +219,14 @@ def test_search_matches_oracle(gpu_ctx, n, d, bq, k):
 
 @pytest.mark.parametrize("n,d,bq,k,with_keys", [(600_000, 64, 256, 5, False), (400_000, 128, 300, 10, True),
                                                  (300_000, 64, 64, 16, False), (500_000, 64, 256, 5, True),
-                                                 (262_144 + 77, 192, 129, 5, False)])
+                                                 (262_144 + 77, 192, 129, 5, False),
+                                                 (2_200_000, 64, 50, 10, True), (280_000, 64, 2000, 5, False)])
 def test_search_long_scan_matches_oracle(gpu_ctx, n, d, bq, k, with_keys):
     """Many gallery tiles per block (the running top-k lists, their pruning thresholds and the
     merge of 256 block lists all matter), every query-tile width, duplicates that tie, a key filter
-    with tombstones, and a last tile that is partly past the end of the gallery."""
+    with tombstones, and a last tile that is partly past the end of the gallery.  In the last two
+    cases every block walks more than 32 tiles, which turns on the score bounds that the blocks
+    share through device memory (one query tile with 256 walkers; eight query tiles with 32)."""
     from frhot import synth
     from frhot.engine import Gallery
     from oracle import search as osr
