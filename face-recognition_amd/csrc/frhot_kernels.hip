@@ -557,6 +557,14 @@ FR_DEV unsigned group_umax(unsigned v) {
     return v;
 }
 
+// max(a, b, c) as one instruction.  Written as the instruction itself: through fmaxf the compiler
+// first re-canonicalises every MFMA result (one more VALU operation per score).
+FR_DEV float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int K>
 struct TopK {
     float s[K];
@@ -1520,6 +1528,19 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                     // one query column group at a time: interleaving the groups would need their
                     // temporaries live together, beside 128 accumulators and the lists
                     __builtin_amdgcn_sched_barrier(0);
+                    // The common case once the lists' tails carry a good bound: no lane's best of its
+                    // 4*NX scores beats its own tail.  One three-input max per two scores.
+                    {
+                        const float4v (&a)[NX] = acc[y];
+                        float mq = max3_raw(a[0][0], a[0][1], a[0][2]);
+                        mq = max3_raw(mq, a[0][3], a[0][3]);
+#pragma unroll
+                        for (int x = 1; x < NX; ++x) {
+                            mq = max3_raw(mq, a[x][0], a[x][1]);
+                            mq = max3_raw(mq, a[x][2], a[x][3]);
+                        }
+                        if (!__any(mq > top[y].s[K - 1])) continue;
+                    }
                     // Lower bounds on the K-th best score of the query over the four lanes' lists:
                     // (a) any lane's own K-th best; (b) min(best (KA+1)-th of any lane, worst
                     // (KB+1)-th of all lanes): the lane that supplies the first term holds KA+1
