@@ -1375,7 +1375,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     // distance that goes into the scalar part of the address, so one register serves all pieces;
     // query rows past Bq are clamped to the last row (their columns are never written out).
     const unsigned xo0 = (unsigned)((8 * wave + (lane >> 3)) * D * 2 + cb);
-    const unsigned yo0 = (unsigned)(q0 + 8 * wave + (lane >> 3)) * (unsigned)D * 2u + (unsigned)cb;
+    // the query block's offsets are the gallery tile's plus the query tile's first row (a uniform
+    // term): they are rebuilt from xo0 at every use instead of occupying a register of their own
+    const unsigned yq0 = (unsigned)q0 * (unsigned)D * 2u;
     const unsigned yomax = (unsigned)(Bq - 1) * (unsigned)D * 2u + (unsigned)cb;
     const unsigned pstride = 64u * (unsigned)D * 2u;
     TopK<K> top[NY];
@@ -1405,8 +1407,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
             if (++iks == nk) { iks = 0; itile += nb; }
         };
         auto issue_y = [&](int slot) __attribute__((always_inline)) {
-            unsigned yb = yo0;
+            unsigned yb = xo0;
             asm volatile("" : "+v"(yb));        // as above: the clamped offsets are recomputed, not kept
+            yb += yq0;
 #pragma unroll
             for (int i = 0; i < NPY; ++i) {
                 unsigned o = yb + (unsigned)i * pstride;
