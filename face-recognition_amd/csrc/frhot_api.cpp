@@ -394,7 +394,8 @@ static int ctx_init(frhot_ctx* c) {
 int frhot_ctx_create(int device_id, void* stream, int max_batch, frhot_ctx** out) {
     if (!out) return fail(FRHOT_EINVAL, "out is null");
     *out = nullptr;
-    if (max_batch <= 0 || max_batch > 4096) return fail(FRHOT_EINVAL, "max_batch %d outside 1..4096", max_batch);
+    // 2048: the conv kernels address a layer's input with 32-bit byte offsets (conv3_2: 1.72 MB per face)
+    if (max_batch <= 0 || max_batch > 2048) return fail(FRHOT_EINVAL, "max_batch %d outside 1..2048", max_batch);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(FRHOT_EINVAL, "device %d of %d", device_id, ndev);

@@ -1857,6 +1857,8 @@ static hipError_t launch_conv_inst(const void* x, const void* w, const float* bi
     if (set_attr_only)
         return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long M = (long)B * HW * HW;
+    // the kernel addresses its input with 32-bit byte offsets per lane
+    if ((unsigned long long)B * (HW + 2) * (HW + 2) * CIN * 2ull >= (1ull << 32)) return hipErrorInvalidValue;
     const long ntiles = ((M + 255) / 256) * (COUT / RY);
     long grid = 256;                       // one walker per CU; a multiple of COUT / RY
     if (grid > ntiles) grid = (ntiles + 1) & ~1L;

@@ -57,7 +57,8 @@ const char* frhot_version(void);
 /*
  * Context = one GPU + one stream + the model + activation workspace.
  * `stream` is a hipStream_t to enqueue on (NULL: the library creates its own).
- * `max_batch` bounds the crops one frhot_embed* call may carry.
+ * `max_batch` (1..2048) bounds the crops one frhot_embed* call may carry; larger
+ * batches go out as several calls.
  * Replaces: the per-process DeepFace model singleton warmed up in
  * app/src/api/app.py:112-118.
  */
