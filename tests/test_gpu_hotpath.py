@@ -172,6 +172,29 @@ def test_embed_full_batch(gpu_ctx, weights_f32):
     assert cosine_rows(got[sample], ref).min() >= 0.9999
 
 
+def test_embed_largest_batch(weights_f32):
+    """The largest batch a context accepts (2048 crops: layer inputs of up to 13 GB, the ring
+    kernels' 32-bit input offsets at 3.5 of their 4 GiB): every descriptor equals, bit for bit,
+    the one its crop gets in a batch of 32; one crop more is refused."""
+    from frhot import synth
+    from frhot._lib import FrhotError
+    from frhot.engine import Context
+    from frhot.weights import pack_blob
+    base = synth.crops(seed=5, n=32, lo=112, hi=180)
+    with pytest.raises(FrhotError):
+        Context(device=0, max_batch=2049)
+    big = Context(device=0, max_batch=2048)
+    try:
+        big.load_model(pack_blob(weights_f32), input_scale=1.0 / 16.0)
+        want = big.embed(base, gamma=True)
+        order = np.random.default_rng(9).permutation(2048) % 32
+        got = big.embed([base[i] for i in order], gamma=True)
+    finally:
+        big.close()
+    assert got.shape == (2048, 4096) and np.isfinite(got).all()
+    assert np.array_equal(got, want[order])
+
+
 def _check_topk(got_s, got_r, ref_s, ref_r, full_scores=None, tol=1e-4):
     """Identical id lists except inside score ties within tol."""
     assert got_r.shape == ref_r.shape
