@@ -82,6 +82,22 @@ def test_resize_matches_float_bilinear_within_one_lsb():
     assert np.abs(got - ref).max() <= 1.0
 
 
+def test_resize_agrees_with_an_independent_bilinear():
+    """torch's bilinear interpolation (half-pixel centres, edge clamp, no antialiasing: the convention
+    cv2.INTER_LINEAR follows) is code this repository did not write; the fixed-point restatement stays
+    within one grey level of it for enlargements and for reductions other than the exact 2x area case."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(7)
+    for (h, w, dh, dw) in [(83, 131, 141, 224), (300, 180, 224, 134), (224, 97, 224, 97), (500, 640, 175, 224),
+                           (31, 29, 224, 209), (449, 447, 224, 223)]:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        got = op.resize_linear_u8(img, dw, dh).astype(np.float64)
+        t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+        ref = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - ref).max() <= 1.0, (h, w, dh, dw, np.abs(got - ref).max())
+
+
 def test_pad_is_centred_and_becomes_minus_mean():
     img = np.full((100, 50, 3), 200, np.uint8)
     u8 = op.resize_pad_u8(img)
