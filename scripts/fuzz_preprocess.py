@@ -42,6 +42,8 @@ def main():
         imgs = []
         for _ in range(8):
             h, w = rand_dim(rng), rand_dim(rng)
+            while min(op.fit_size(h, w)) <= 0:                  # resizes to nothing: refused, like cv2 refuses it
+                h, w = rand_dim(rng), rand_dim(rng)
             style = rng.integers(0, 4)
             if style == 0:
                 im = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
