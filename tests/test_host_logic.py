@@ -341,3 +341,72 @@ def test_search_batcher_groups_concurrent_searches():
         assert np.allclose([x["score"] for x in g], [x["score"] for x in r], atol=1e-6)
     assert sum(calls) == n_unbatched and len(calls) < 5      # 40 real scans' worth of queries in a few calls
     assert sb.items == len(reqs) and sb.batches < 5
+
+
+def test_keras_h5_converter_layout(monkeypatch):
+    """from_keras_h5 against a stand-in for h5py that serves a Keras-style file: kernels stored
+    [kh, kw, Cin, Cout] come out [Cout, kh, kw, Cin], in layer order, fc8 ignored, fc7 as a matrix.
+    (h5py and vgg_face_weights.h5 do not exist in this image; the stand-in has h5py's File / group /
+    attrs shape and nothing else.)"""
+    import sys
+    import types
+    from frhot.weights import LAYERS, from_keras_h5, pack_blob
+
+    rng = np.random.default_rng(0)
+    store, names = {}, []
+
+    def add(name, arrays):
+        names.append(name.encode())
+        g = types.SimpleNamespace(attrs={"weight_names": [f"{name}/{k}".encode() for k in arrays]}, data={
+            f"{name}/{k}": v for k, v in arrays.items()})
+        store[name] = g
+
+    class Group:
+        def __init__(self, g):
+            self.attrs, self._d = g.attrs, g.data
+
+        def __getitem__(self, k):
+            return self._d[k]
+
+    class File:
+        def __init__(self, path, mode):
+            self.attrs = {"layer_names": names}
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __getitem__(self, k):
+            return Group(store[k])
+
+    add("zero_padding2d_1", {})                                   # layers without weights are skipped
+    kernels = {}
+    for (name, kh, kw, cin, cout) in LAYERS:
+        if name == "fc6":                                         # 411 MB as float32: a repeating pattern
+            k = np.broadcast_to(rng.standard_normal((kh, kw, cin, 1), dtype=np.float32), (kh, kw, cin, cout))
+        else:
+            k = rng.standard_normal((kh, kw, cin, cout), dtype=np.float32)
+        kernels[name] = k
+        add(name, {"kernel:0": k, "bias:0": np.arange(cout, dtype=np.float32)})
+        add(name + "_relu", {})
+    add("fc8", {"kernel:0": np.zeros((1, 1, 4096, 2622), np.float32), "bias:0": np.zeros(2622, np.float32)})
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    out = from_keras_h5("vgg_face_weights.h5")
+    assert out["conv1_1.w"].shape == (64, 3, 3, 3) and out["fc6.w"].shape == (4096, 7, 7, 512)
+    assert out["fc7.w"].shape == (4096, 4096)
+    k = kernels["conv3_2"]
+    assert out["conv3_2.w"][17, 2, 0, 100] == k[2, 0, 100, 17] and out["conv3_2.w"][255, 1, 1, 0] == k[1, 1, 0, 255]
+    assert out["fc6.w"][9, 6, 5, 300] == kernels["fc6"][6, 5, 300, 9]
+    assert out["fc7.w"][5, 77] == kernels["fc7"][0, 0, 77, 5]
+    assert np.array_equal(out["conv5_3.b"], np.arange(512, dtype=np.float32))
+    # a Keras convolution with kernel k equals the oracle's convolution with the converted weight
+    import torch
+    import torch.nn.functional as F
+    x = torch.from_numpy(rng.standard_normal((1, 64, 6, 6), dtype=np.float32))
+    kk = kernels["conv1_2"]
+    keras = F.conv2d(x, torch.from_numpy(np.ascontiguousarray(kk.transpose(3, 2, 0, 1))), padding=1)    # HWIO -> OIHW
+    ours = F.conv2d(x, torch.from_numpy(out["conv1_2.w"]).permute(0, 3, 1, 2), padding=1)               # KRSC -> OIHW
+    assert torch.equal(keras, ours)
+    assert pack_blob(out).size > 268_000_000
