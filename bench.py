@@ -187,7 +187,7 @@ def main():
         res_r = last["r"].cpu().numpy()
         sane = bool((res_r >= 0).all() and (np.diff(res_s, axis=1) <= 0).all() and np.isfinite(res_s).all())
 
-        # Secondary measurement on rank 0: the HBM-bound scan shape of BASELINE.json configs[1]
+        # Secondary measurement on rank 0: the HBM-bound scan-only shape
         # (1M x 512 fp16 gallery, 64 queries, top-10), timed with the library's stream events.
         scan64 = None
         if rank == 0 and not args.no_scan64:
