@@ -62,6 +62,7 @@ int scan_max_blocks();
 // g_f16 / g_keys must be allocated in whole tiles of 256 rows (reads run to the tile end).
 // qbound: scan_bound_bytes(Bq) bytes of device scratch (cross-block score bounds), or null.
 size_t scan_bound_bytes(int Bq);
+void scan_set_bound_min_tiles(int tiles);   // blocks that walk fewer tiles scan without the bounds (< 0: built-in rule)
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
                             float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s);

@@ -2060,6 +2060,9 @@ static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const 
 
 // `use_keys`: apply the per-row key test (needed when query keys are given or the gallery
 // may hold dead rows).  The gallery buffers must be padded to a multiple of 256 rows.
+static int g_bound_min_tiles = -1;       // < 0: the built-in rule below
+void scan_set_bound_min_tiles(int t) { g_bound_min_tiles = t; }      // tuning hook of the micro-benchmark
+
 size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 16 * sizeof(unsigned); }
 
 // `qbound`: scan_bound_bytes(Bq) bytes of device scratch for the cross-block score bounds (cleared
@@ -2081,8 +2084,11 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
     const long nt8 = (ntiles + 7) & ~7L;
     if (nb > nt8) nb = (int)nt8;
     *nblk_out = nb;
-    // the bounds pay once a block walks enough tiles to amortise their reads (and the clearing launch)
-    if (ntiles / nb < 32) qbound = nullptr;
+    // The bounds pay once a block walks enough tiles to amortise their reads (and the clearing launch):
+    // measured break-even near 20 tiles for the HBM-bound 64-query tile and below 8 for the wider,
+    // MFMA-bound tiles, whose tile-end selection the bounds shorten most.
+    const int min_tiles = g_bound_min_tiles >= 0 ? g_bound_min_tiles : (ry >= 128 ? 8 : 24);
+    if (ntiles / nb < min_tiles) qbound = nullptr;
     if (qbound) {
         hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq), s);
         if (e != hipSuccess) return e;

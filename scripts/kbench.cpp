@@ -200,9 +200,22 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
 static void bench_scan() {
     hipStream_t s;
     CK(hipStreamCreate(&s));
+    if (getenv("KBENCH_BOUND_MIN_TILES")) {
+        scan_set_bound_min_tiles(atoi(getenv("KBENCH_BOUND_MIN_TILES")));
+        for (long n : {1000000L, 2000000L, 4000000L}) {
+            bench_scan_one(n, 512, 64, 5, 0, s);
+            bench_scan_one(n, 512, 64, 10, 0, s);
+            bench_scan_one(n, 512, 256, 5, 0, s);
+        }
+        CK(hipStreamDestroy(s));
+        return;
+    }
     bench_scan_one(1000000, 512, 64, 10, 0, s);
     bench_scan_one(1000000, 512, 64, 5, 0, s);
     bench_scan_one(10000000, 512, 64, 5, 0, s);
+    bench_scan_one(10000000, 512, 64, 10, 0, s);
+    bench_scan_one(10000000, 512, 64, 16, 0, s);
+    bench_scan_one(10000000, 512, 128, 10, 0, s);
     bench_scan_one(10000000, 512, 128, 5, 0, s);
     bench_scan_one(10000000, 512, 256, 5, 0, s);
     bench_scan_one(10000000, 512, 256, 5, 1, s);

@@ -247,9 +247,10 @@ def test_search_matches_oracle(gpu_ctx, n, d, bq, k):
 def test_search_long_scan_matches_oracle(gpu_ctx, n, d, bq, k, with_keys):
     """Many gallery tiles per block (the running top-k lists, their pruning thresholds and the
     merge of 256 block lists all matter), every query-tile width, duplicates that tie, a key filter
-    with tombstones, and a last tile that is partly past the end of the gallery.  In the last two
-    cases every block walks more than 32 tiles, which turns on the score bounds that the blocks
-    share through device memory (one query tile with 256 walkers; eight query tiles with 32)."""
+    with tombstones, and a last tile that is partly past the end of the gallery.  Several
+    cases give a block enough tiles (8 for the wide query tiles, 24 for the 64-query tile) to turn on the
+    score bounds that the blocks share through device memory, among them one query tile with 256
+    walkers and eight query tiles with 32."""
     from frhot import synth
     from frhot.engine import Gallery
     from oracle import search as osr
