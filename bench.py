@@ -110,6 +110,12 @@ def pmc_traffic(rows, dim, queries, k):
 
 def main():
     args = parse()
+    # Native libraries write to the process's stdout behind Python's back (RCCL prints a version
+    # banner when its communicator is created).  Everything this process prints goes to stderr;
+    # the one JSON line is written to the original stdout at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,8 +131,12 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["FRHOT_BENCH_WATCHDOG_S"]), exit=True)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # FRHOT_BENCH_REHEARSE_DIST=1 with one rank: a one-rank RCCL group, and the gathers and the merge of the
+    # multi-rank step run anyway (what a one-GPU box can rehearse of the N > 1 path)
+    rehearse = world == 1 and bool(os.environ.get("FRHOT_BENCH_REHEARSE_DIST"))
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from frhot import synth
@@ -155,7 +165,7 @@ def main():
         def merge(s_all, r_all, out_s, out_r):
             ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, P * B, K, out_s.data_ptr(), out_r.data_ptr())
 
-        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge)
+        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse)
         last = {}
 
         def step():
@@ -165,19 +175,19 @@ def main():
         for _ in range(args.warmup):
             step()
         ctx.timing(True)
-        if P > 1:
+        if P > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if P > 1:
+        if P > 1 or rehearse:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         stages = ctx.stage_ms()
         ctx.timing(False)
-        if P > 1:
+        if P > 1 or rehearse:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -255,11 +265,13 @@ def main():
                 line["gates"] = gates
         gal.close()
         ctx.close()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if line is not None:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -23,16 +23,19 @@ import torch.distributed as dist
 
 class ShardedSearch:
     def __init__(self, world: int, batch: int, dim: int, k: int, device,
-                 search_local: Callable, merge: Callable, qdtype=torch.float16):
+                 search_local: Callable, merge: Callable, qdtype=torch.float16, always_exchange: bool = False):
         """search_local(q_all, scores_out, rows_out): fill [P*B,k] float32 / int64 (global rows, -1 = none).
         merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
         self.P, self.B, self.D, self.k = world, batch, dim, k
         self.search_local, self.merge = search_local, merge
+        # always_exchange: run the gathers and the merge even with one rank (a rehearsal of the
+        # multi-rank code path on a single GPU)
+        self.exchange = world > 1 or always_exchange
         n = world * batch
-        self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if world > 1 else None
+        self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if self.exchange else None
         self.s_local = torch.empty((n, k), dtype=torch.float32, device=device)
         self.r_local = torch.empty((n, k), dtype=torch.int64, device=device)
-        if world > 1:
+        if self.exchange:
             self.s_all = torch.empty((world, n, k), dtype=torch.float32, device=device)
             self.r_all = torch.empty((world, n, k), dtype=torch.int64, device=device)
             self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
@@ -40,7 +43,7 @@ class ShardedSearch:
 
     def __call__(self, q_local: torch.Tensor):
         """q_local [B, D] unit rows of this rank -> (scores [P*B,k], rows [P*B,k]) for every rank's queries."""
-        if self.P == 1:
+        if not self.exchange:
             self.search_local(q_local, self.s_local, self.r_local)
             return self.s_local, self.r_local
         dist.all_gather_into_tensor(self.q_all, q_local)
