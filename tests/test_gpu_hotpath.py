@@ -555,3 +555,53 @@ def test_api_end_to_end_concurrent_requests(gpu_ctx):
         app.state.gallery_service.close()
         from frhot import legacy
         legacy.install_engine(None)
+
+
+def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
+    """The multi-rank step (all-gather of queries, shard scan with a row base, all-gathers of the
+    shard lists, merge) through a one-rank RCCL group on the library's stream: what one GPU can
+    exercise of the N > 1 path.  Equals a plain search of the same gallery."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from frhot import synth
+    from frhot.dist import ShardedSearch
+    from frhot.engine import Gallery
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n, d, b, k, base = 50_000, 512, 24, 5, 1_000_000
+    g = synth.unit_gallery(seed=4, n=n, d=d)
+    q = synth.planted_queries(np.random.default_rng(2), g[:b], 0.8)
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, 0, np.arange(n))
+    want_s, want_r = gal.search(q, None, k)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        q16 = torch.from_numpy(q.astype(np.float16)).to(dev)
+
+        def search_local(q_all, s_out, r_out):
+            gal.search_dev(q_all.data_ptr(), None, q_all.shape[0], k, s_out.data_ptr(), r_out.data_ptr(), base)
+
+        def merge(s_all, r_all, out_s, out_r):
+            gpu_ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), 1, b, k, out_s.data_ptr(), out_r.data_ptr())
+
+        sharded = ShardedSearch(1, b, d, k, dev, search_local, merge, always_exchange=True)
+        torch.cuda.synchronize()
+        out_s, out_r = sharded(q16)
+        gpu_ctx.sync()
+        torch.cuda.synchronize()
+        got_s, got_r = out_s.cpu().numpy(), out_r.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+        gal.close()
+    assert np.array_equal(got_r, want_r + base)
+    assert np.abs(got_s - want_s).max() <= 2e-3        # the host call normalises float32 queries; here they arrive as fp16
