@@ -20,93 +20,32 @@ from concurrent.futures import Future
 import numpy as np
 
 
-class EmbedBatcher:
-    def __init__(self, ctx, max_batch: int | None = None, max_delay_s: float = 0.002):
-        self.ctx = ctx
-        self.max_batch = min(max_batch or ctx.max_batch, ctx.max_batch)
-        self.max_delay_s = max_delay_s
-        self._q: queue.Queue = queue.Queue()
-        self._stop = threading.Event()
-        self.batches = 0
-        self.items = 0
-        self._thread = threading.Thread(target=self._run, name="frhot-batcher", daemon=True)
-        self._thread.start()
+class _MicroBatcher:
+    """Queue + dispatcher thread: collects items for at most `max_delay_s` (or until `max_batch`
+    wait) and hands the batch to `_dispatch`, which resolves every item's future."""
 
-    def submit(self, crop: np.ndarray, gamma: bool = False) -> Future:
-        """Queue one uint8 BGR crop; the future resolves to its float32 [4096] unit descriptor."""
-        fut: Future = Future()
-        self._q.put((crop, bool(gamma), fut))
-        return fut
-
-    def embed(self, crop: np.ndarray, gamma: bool = False, timeout: float | None = 60.0) -> np.ndarray:
-        return self.submit(crop, gamma).result(timeout=timeout)
-
-    def close(self):
-        self._stop.set()
-        self._q.put(None)
-        self._thread.join(timeout=5.0)
-
-    def _run(self):
-        while not self._stop.is_set():
-            item = self._q.get()
-            if item is None:
-                continue
-            batch = [item]
-            deadline = time.monotonic() + self.max_delay_s
-            while len(batch) < self.max_batch:
-                left = deadline - time.monotonic()
-                if left <= 0:
-                    break
-                try:
-                    nxt = self._q.get(timeout=left)
-                except queue.Empty:
-                    break
-                if nxt is None:
-                    break
-                batch.append(nxt)
-            # one device call per gamma setting (a flag of the whole batch)
-            for flag in (False, True):
-                group = [b for b in batch if b[1] == flag]
-                if not group:
-                    continue
-                try:
-                    out = self.ctx.embed([g[0] for g in group], gamma=flag)
-                    for g, row in zip(group, out):
-                        g[2].set_result(row.copy())
-                except Exception as e:  # every waiter sees the failure
-                    for g in group:
-                        g[2].set_exception(e)
-                self.batches += 1
-                self.items += len(group)
-
-
-class SearchBatcher:
-    """Groups concurrent search_point calls into one GalleryService.search_points call."""
-
-    def __init__(self, service, max_batch: int = 256, max_delay_s: float = 0.002):
-        self.service = service
+    def __init__(self, max_batch: int, max_delay_s: float, name: str):
         self.max_batch = max_batch
         self.max_delay_s = max_delay_s
         self._q: queue.Queue = queue.Queue()
         self._stop = threading.Event()
         self.batches = 0
         self.items = 0
-        self._thread = threading.Thread(target=self._run, name="frhot-search-batcher", daemon=True)
+        self._thread = threading.Thread(target=self._run, name=name, daemon=True)
         self._thread.start()
 
-    def submit(self, collection_name, vector_embedding, store_id) -> Future:
-        """Queue one search; the future resolves to the service's (status_code, content)."""
+    def _put(self, payload) -> Future:
         fut: Future = Future()
-        self._q.put(((collection_name, vector_embedding, store_id), fut))
+        self._q.put((payload, fut))
         return fut
-
-    def search_point(self, collection_name, vector_embedding, store_id, timeout: float | None = 60.0):
-        return self.submit(collection_name, vector_embedding, store_id).result(timeout=timeout)
 
     def close(self):
         self._stop.set()
         self._q.put(None)
         self._thread.join(timeout=5.0)
+
+    def _dispatch(self, batch):          # batch: list of (payload, future)
+        raise NotImplementedError
 
     def _run(self):
         while not self._stop.is_set():
@@ -127,12 +66,61 @@ class SearchBatcher:
                     break
                 batch.append(nxt)
             try:
-                answers = self.service.search_points([b[0] for b in batch])
-                for b, ans in zip(batch, answers):
-                    b[1].set_result(ans)
+                self._dispatch(batch)
             except Exception as e:  # every waiter sees the failure
-                for b in batch:
-                    if not b[1].done():
-                        b[1].set_exception(e)
+                for _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(e)
+
+
+class EmbedBatcher(_MicroBatcher):
+    """Groups concurrent single-crop embeds into one frhot_embed per gamma setting."""
+
+    def __init__(self, ctx, max_batch: int | None = None, max_delay_s: float = 0.002):
+        self.ctx = ctx
+        super().__init__(min(max_batch or ctx.max_batch, ctx.max_batch), max_delay_s, "frhot-batcher")
+
+    def submit(self, crop: np.ndarray, gamma: bool = False) -> Future:
+        """Queue one uint8 BGR crop; the future resolves to its float32 [4096] unit descriptor."""
+        return self._put((crop, bool(gamma)))
+
+    def embed(self, crop: np.ndarray, gamma: bool = False, timeout: float | None = 60.0) -> np.ndarray:
+        return self.submit(crop, gamma).result(timeout=timeout)
+
+    def _dispatch(self, batch):
+        # one device call per gamma setting (a flag of the whole batch)
+        for flag in (False, True):
+            group = [b for b in batch if b[0][1] == flag]
+            if not group:
+                continue
+            try:
+                out = self.ctx.embed([g[0][0] for g in group], gamma=flag)
+                for g, row in zip(group, out):
+                    g[1].set_result(row.copy())
+            except Exception as e:
+                for g in group:
+                    g[1].set_exception(e)
             self.batches += 1
-            self.items += len(batch)
+            self.items += len(group)
+
+
+class SearchBatcher(_MicroBatcher):
+    """Groups concurrent search_point calls into one GalleryService.search_points call."""
+
+    def __init__(self, service, max_batch: int = 256, max_delay_s: float = 0.002):
+        self.service = service
+        super().__init__(max_batch, max_delay_s, "frhot-search-batcher")
+
+    def submit(self, collection_name, vector_embedding, store_id) -> Future:
+        """Queue one search; the future resolves to the service's (status_code, content)."""
+        return self._put((collection_name, vector_embedding, store_id))
+
+    def search_point(self, collection_name, vector_embedding, store_id, timeout: float | None = 60.0):
+        return self.submit(collection_name, vector_embedding, store_id).result(timeout=timeout)
+
+    def _dispatch(self, batch):
+        answers = self.service.search_points([b[0] for b in batch])
+        for b, ans in zip(batch, answers):
+            b[1].set_result(ans)
+        self.batches += 1
+        self.items += len(batch)
