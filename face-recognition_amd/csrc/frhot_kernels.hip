@@ -1492,6 +1492,23 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                 // from zero anyway): the selection then reads the accumulators themselves and needs no copy.
                 // Key test: (key ^ kx) <= km as unsigned, with (kx, km) = (query key, 0) for an exact
                 // match and (0, 0x7fffffff) for "any live row" (tombstones are negative).
+                // Nothing below can change a list unless some lane's best raw score beats its own tail
+                // (striking rows out only lowers scores): the usual tile, once the tails carry a good
+                // bound, ends here without fetching a key.
+                bool some = !USE_KEYS;       // without keys the per-query test below is this same test
+#pragma unroll
+                for (int y = 0; USE_KEYS && y < NY; ++y) {
+                    const float4v (&a)[NX] = acc[y];
+                    float mq = max3_raw(a[0][0], a[0][1], a[0][2]);
+                    mq = max3_raw(mq, a[0][3], a[0][3]);
+#pragma unroll
+                    for (int x = 1; x < NX; ++x) {
+                        mq = max3_raw(mq, a[x][0], a[x][1]);
+                        mq = max3_raw(mq, a[x][2], a[x][3]);
+                    }
+                    some = some || __any(mq > top[y].s[K - 1]);
+                }
+                if (some) {
                 if (USE_KEYS) {
                     int4 kv[NX];
 #pragma unroll
@@ -1624,6 +1641,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         m = want ? m2 : -INFINITY;     // a lane with nothing to insert is done with this tile
                     }
                 }
+                }   // some
                 // Cross-block bound.  A lane's list sees 1/(4*WX*nb) of the rows, so its own K-th best
                 // is a weak filter and, without more, nearly every tile finds some lane with a score
                 // to insert.  qbound holds K slots per query; every wave of every block belongs to
