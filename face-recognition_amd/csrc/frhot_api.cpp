@@ -288,22 +288,38 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     return FRHOT_OK;
 }
 
+// Answer of a search over an empty gallery: -inf / -1 everywhere, by two fills on the stream.
+int search_fill_empty(hipStream_t s, int Bq, int k, float* scores_dev, int64_t* rows_dev) {
+    HIP_TRY(hipMemsetAsync(rows_dev, 0xFF, sizeof(int64_t) * (size_t)Bq * k, s));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)scores_dev, (int)0xFF800000u, (size_t)Bq * k, s));   // -inf
+    return FRHOT_OK;
+}
+
+// Scan + final selection with the candidate lists in part_s / part_r and the score bounds in qbound.
+int search_launch(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, int Bq, int k, float* scores_dev,
+                  int64_t* rows_dev, int64_t row_base, float* part_s, int64_t* part_r, unsigned* qbound) {
+    frhot_ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    const int kl = scan_list_len(k);
+    int nblk = 0;
+    if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
+    const int use_keys = (qkeys_dev != nullptr || !g->dense) ? 1 : 0;
+    HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, use_keys, Bq, k, part_s, part_r,
+                             qbound, &nblk, s));
+    if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
+    HIP_TRY(launch_topk_final(part_s, part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
+    if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
+    return FRHOT_OK;
+}
+
 int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, int Bq, int k, float* scores_dev,
                    int64_t* rows_dev, int64_t row_base) {
     frhot_ctx* c = g->ctx;
     if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
     if (!q16 || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null search arguments");
     hipStream_t s = c->stream;
-    if (g->nrows == 0) {
-        // nothing stored: -inf / -1 everywhere, via the final kernel over one empty list
-        HIP_TRY(hipMemsetAsync(rows_dev, 0xFF, sizeof(int64_t) * (size_t)Bq * k, s));
-        std::vector<float> ninf((size_t)Bq * k, -INFINITY);
-        HIP_TRY(hipMemcpyAsync(scores_dev, ninf.data(), sizeof(float) * ninf.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        return FRHOT_OK;
-    }
-    const int kl = scan_list_len(k);
-    const size_t need = (size_t)scan_max_blocks() * Bq * kl;
+    if (g->nrows == 0) return search_fill_empty(s, Bq, k, scores_dev, rows_dev);
+    const size_t need = scan_part_entries(Bq, k);
     if (need > g->part_cap) {
         HIP_TRY(hipStreamSynchronize(s));
         g->part_cap = 0;
@@ -321,15 +337,7 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
         HIP_TRY(hipMalloc((void**)&g->qbound, cap));
         g->qbound_cap = cap;
     }
-    int nblk = 0;
-    if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
-    const int use_keys = (qkeys_dev != nullptr || !g->dense) ? 1 : 0;
-    HIP_TRY(launch_scan_topk(g->rows, g->keys, g->nrows, g->D, q16, qkeys_dev, use_keys, Bq, k, g->part_s, g->part_r,
-                             g->qbound, &nblk, s));
-    if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
-    HIP_TRY(launch_topk_final(g->part_s, g->part_r, nblk, kl, Bq, k, row_base, scores_dev, rows_dev, s));
-    if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
-    return FRHOT_OK;
+    return search_launch(g, q16, qkeys_dev, Bq, k, scores_dev, rows_dev, row_base, g->part_s, g->part_r, g->qbound);
 }
 
 int gallery_grow_query_staging(frhot_gallery* g, int Bq) {
@@ -731,6 +739,27 @@ int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qke
     std::lock_guard<std::mutex> lk(g->ctx->mu);
     DeviceGuard dg(g->ctx->device);
     return search_enqueue(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base);
+}
+
+int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev, int Bq, int k,
+                            void* scores_dev, void* rows_dev, int64_t row_base) {
+    if (!g) return fail(FRHOT_EINVAL, "gallery is null");
+    if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
+    if (!q_f16_dev || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null search arguments");
+    frhot_ctx* c = g->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    ScanStaticScratch sc;
+    HIP_TRY(scan_static_scratch(c->device, &sc));
+    const size_t need = scan_part_entries(Bq, k);
+    if (need > sc.entries || scan_bound_bytes(Bq) > sc.bound_bytes)
+        return fail(FRHOT_ECAPACITY,
+                    "%d queries of top-%d need %zu candidate entries and %zu bound bytes; the static scratch holds "
+                    "%zu and %zu (8192 queries of top-5, 4096 of top-10, 2048 of top-16)",
+                    Bq, k, need, scan_bound_bytes(Bq), sc.entries, sc.bound_bytes);
+    if (g->nrows == 0) return search_fill_empty(c->stream, Bq, k, (float*)scores_dev, (int64_t*)rows_dev);
+    return search_launch(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base, sc.part_s,
+                         sc.part_r, sc.qbound);
 }
 
 int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq, int k, float* scores, int64_t* rows) {

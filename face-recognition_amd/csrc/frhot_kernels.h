@@ -66,12 +66,25 @@ void scan_set_bound_min_tiles(int tiles);   // blocks that walk fewer tiles scan
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
                             float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s);
+// Upper bound on the list entries (one score and one row each) launch_scan_topk writes to
+// part_s / part_r for Bq queries of top-k, whatever the gallery size.
+size_t scan_part_entries(int Bq, int k);
+// The static device scratch of the allocation-free search (a file-scope __device__ array of the
+// code object; every GPU holds its own copy).  Valid after kernels_init() ran with `device` current.
+struct ScanStaticScratch {
+    float* part_s; int64_t* part_r; unsigned* qbound;
+    size_t entries;       // list entries part_s / part_r hold
+    size_t bound_bytes;   // bytes behind qbound
+};
+hipError_t scan_static_scratch(int device, ScanStaticScratch* out);
 // Length of the per-block candidate lists the scan writes for a request of k (5, 10 or 16).
 int scan_list_len(int k);
 // Final selection over nlists lists of kin (layout [nlists][Bq][kin]) -> best kout per query.
 hipError_t launch_topk_final(const float* cand_s, const int64_t* cand_r, int nlists, int kin, int Bq, int kout,
                              int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s);
 
-hipError_t kernels_init();  // sets dynamic-LDS attributes once per process
+// Sets the dynamic-LDS attributes and resolves the static scratch's address on the CURRENT device;
+// call once per device (repeat calls are cheap).
+hipError_t kernels_init();
 
 }  // namespace frhot

@@ -14,6 +14,7 @@
 // ds_read_b128, v_mfma_f32_16x16x32_f16 accumulation in fp32.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <mutex>
 #include <type_traits>
 #include "frhot_kernels.h"
 
@@ -2041,6 +2042,67 @@ static int scan_query_tile(int Bq, int kl) {
     return want < cap ? want : cap;
 }
 
+// Gallery walkers per query tile before the clamp to the gallery's tile count.
+static int scan_walkers(int qtiles) {
+    const int nb = (scan_max_blocks() / qtiles) & ~7;
+    return nb < 8 ? 8 : nb;
+}
+
+size_t scan_part_entries(int Bq, int k) {
+    const int kl = scan_klist(k);
+    const int ry = scan_query_tile(Bq, kl);
+    return (size_t)scan_walkers((Bq + ry - 1) / ry) * (size_t)Bq * (size_t)kl;
+}
+
+// Scratch of the search entry point that allocates nothing: the per-block candidate lists of the
+// scan (rows, then scores) and the cross-block score bounds, one copy per GPU that loads this
+// code object, held until the process ends.  kScanStaticEntries covers every request whose
+// walkers x queries x list length stays at 256 blocks of 256 top-5 lists (up to 8192 queries of
+// top-5, 4096 of top-10, 2048 of top-16); the bounds cover 8192 queries.  Host code never passes
+// the array itself to a kernel or a memset: its name is a host-side stand-in, the device address
+// comes from hipGetSymbolAddress, once per device, below.
+constexpr size_t kScanStaticEntries = 256 * 256 * 5;
+constexpr size_t kScanStaticBoundBytes = 8192 * 16 * sizeof(unsigned);
+constexpr size_t kScanStaticBytes = kScanStaticEntries * (sizeof(int64_t) + sizeof(float)) + kScanStaticBoundBytes;
+static __device__ __align__(256) unsigned char scratch[kScanStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];          // device address of `scratch` on each GPU (0: not resolved yet)
+static std::mutex g_scratch_mu;
+
+// Resolves the address of `scratch` on the CURRENT device (once per device).
+static hipError_t scan_static_resolve() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev]) return hipSuccess;
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p || ((uintptr_t)p & 255u)) return hipErrorInvalidSymbol;
+    g_scratch_ptr[dev] = p;
+    return hipSuccess;
+}
+
+hipError_t scan_static_scratch(int device, ScanStaticScratch* out) {
+    if (!out || device < 0 || device >= kMaxDevices) return hipErrorInvalidValue;
+    void* p;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        p = g_scratch_ptr[device];
+    }
+    if (!p) return hipErrorNotInitialized;        // kernels_init has not run with this device current
+    unsigned char* const b = (unsigned char*)p;
+    out->part_r = (int64_t*)b;
+    out->part_s = (float*)(b + kScanStaticEntries * sizeof(int64_t));
+    out->qbound = (unsigned*)(b + kScanStaticEntries * (sizeof(int64_t) + sizeof(float)));
+    out->entries = kScanStaticEntries;
+    out->bound_bytes = kScanStaticBoundBytes;
+    return hipSuccess;
+}
+
 template <int K, int RY, int WX, int WY, bool USE_KEYS>
 static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
                             int Bq, int nb, float* part_s, int64_t* part_r, unsigned* qbound, hipStream_t s,
@@ -2097,8 +2159,7 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
     const int ry = scan_query_tile(Bq, kl);
     const int qtiles = (Bq + ry - 1) / ry;
     const long ntiles = (nrows + 255) / 256;
-    int nb = (scan_max_blocks() / qtiles) & ~7;
-    if (nb < 8) nb = 8;
+    int nb = scan_walkers(qtiles);
     const long nt8 = (ntiles + 7) & ~7L;
     if (nb > nt8) nb = (int)nt8;
     *nblk_out = nb;
@@ -2135,6 +2196,10 @@ hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int
 }
 
 hipError_t kernels_init() {
+    {
+        const hipError_t es = scan_static_resolve();
+        if (es != hipSuccess) return es;
+    }
     static const ConvLayerDesc layers[] = {
         {224, 64, 64, 1, 1},  {112, 64, 128, 0, 1}, {112, 128, 128, 1, 1}, {56, 128, 256, 0, 1},
         {56, 256, 256, 0, 1}, {56, 256, 256, 1, 1}, {28, 256, 512, 0, 1},  {28, 512, 512, 0, 1},

@@ -44,6 +44,7 @@ SIGNATURES = {
     "frhot_gallery_rows": (C.c_int64, [_p]),
     "frhot_search": (C.c_int, [_p, _f32p, _i32p, C.c_int, C.c_int, _f32p, _i64p]),
     "frhot_search_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
+    "frhot_search_dev_static": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_merge_topk_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),
@@ -61,6 +62,32 @@ class FrhotError(RuntimeError):
         self.message = message
 
 
+def _share_torch_hip_runtime() -> None:
+    """One process, one HIP runtime.  A PyTorch-ROCm wheel ships its own libamdhip64.so (soname
+    libamdhip64.so.7) and asks for it by file name; libfrhot.so asks for the soname.  Loaded
+    torch-first, the dynamic loader hands libfrhot.so torch's copy and both share one runtime;
+    loaded libfrhot-first, it maps the system copy for us and later torch's copy as well, and
+    the second runtime to initialise finds no GPU ("No HIP GPUs are available").  Callers hand
+    torch device pointers to this library, so when a torch wheel with a bundled runtime is
+    installed and not yet imported, its copy is mapped first (no torch import, nothing else of
+    torch is touched); without such a wheel the system runtime serves libfrhot.so alone."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for base in spec.submodule_search_locations:
+        path = os.path.join(base, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load() -> C.CDLL:
     """Load libfrhot.so once and declare every signature.  Raises if it is missing."""
     global _lib
@@ -70,6 +97,7 @@ def load() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C face-recognition_amd` "
             "(there is no fallback implementation)")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

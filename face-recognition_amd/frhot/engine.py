@@ -219,5 +219,11 @@ class Gallery:
         check(self._lib.frhot_search_dev(self._h, C.c_void_p(q_f16_dev), C.c_void_p(qkeys_dev or 0), bq, k,
                                          C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
 
+    def search_dev_static(self, q_f16_dev: int, qkeys_dev: int | None, bq: int, k: int, scores_dev: int,
+                          rows_dev: int, row_base: int = 0):
+        """search_dev without any allocation: the scan's scratch is a static device array."""
+        check(self._lib.frhot_search_dev_static(self._h, C.c_void_p(q_f16_dev), C.c_void_p(qkeys_dev or 0), bq, k,
+                                                C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
+
 
 __all__ = ["Context", "Gallery", "EMBED_DIM", "KEY_ANY"]

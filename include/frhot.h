@@ -182,6 +182,21 @@ int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qke
                      int Bq, int k, void* scores_dev, void* rows_dev, int64_t row_base);
 
 /*
+ * frhot_search_dev for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments, same answer bit for bit; the scan's per-block candidate lists and score
+ * bounds live in a static device array of the library (about 4.5 MB on every GPU the library
+ * runs on, held until the process ends) instead of buffers the gallery grows on demand, and
+ * the call makes no hipMalloc / hipFree / allocating library call.  Limits: walkers x queries x
+ * list length <= 327,680 entries and at most 8192 queries, i.e. up to 8192 queries of top-5,
+ * 4096 of top-10, 2048 of top-16; beyond that FRHOT_ECAPACITY.  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (two contexts, two streams) race; calls on
+ * one context are serialised by its stream as usual.
+ */
+int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev,
+                            int Bq, int k, void* scores_dev, void* rows_dev, int64_t row_base);
+
+/*
  * Merge P per-shard answers (the all-gathered outputs of frhot_search_dev laid
  * out [P,Bq,k]) into the global top-k [Bq,k].  All pointers are device memory.
  * P <= 256; every per-shard list must be in the order frhot_search_dev writes
