@@ -66,6 +66,52 @@ def cosine_topk(q, g, k, keys=None, qkeys=None, gallery_dtype=np.float32, chunk=
     return best_s.astype(np.float32), best_r
 
 
+def _kth_largest(s: np.ndarray, k: int) -> np.ndarray:
+    """Per row of s, its k-th largest value (threaded torch.topk when torch is importable)."""
+    try:
+        import torch
+        return torch.topk(torch.from_numpy(np.ascontiguousarray(s)), k, dim=1).values[:, -1].numpy()
+    except ImportError:
+        n = s.shape[1]
+        return np.partition(s, n - k, axis=1)[:, n - k]
+
+
+def topk_stored(q16, g16, k, keys=None, qkeys=None, chunk=65536, row0=0):
+    """Exact top-k over rows ALREADY in the library's storage format: q16 [Bq,D] and g16 [N,D]
+    are fp16 (or fp16-valued float32) and are scored as they stand, products and sums in
+    float32; nothing is normalised.  Same answer rules as cosine_topk (score descending, ties
+    by ascending row, -1 / -inf padding, key filter), but sized for millions of rows: per
+    chunk only the rows at or above the chunk's k-th best score (all ties included) are kept
+    and sorted.  `row0` is added to the returned rows (a slice of a larger gallery)."""
+    qn = np.ascontiguousarray(q16, dtype=np.float32)
+    Bq, N = qn.shape[0], g16.shape[0]
+    cand_s = [[] for _ in range(Bq)]
+    cand_r = [[] for _ in range(Bq)]
+    qk = None if keys is None else np.asarray(qkeys)[:, None]
+    for lo in range(0, N, chunk):
+        hi = min(N, lo + chunk)
+        s = qn @ np.asarray(g16[lo:hi], dtype=np.float32).T
+        if keys is not None:
+            kk = np.asarray(keys[lo:hi])[None, :]
+            ok = np.where(qk == ANY_KEY, kk >= 0, kk == qk)
+            s = np.where(ok, s, np.float32(-np.inf))
+        kk_ = min(k, hi - lo)
+        thr = _kth_largest(s, kk_)
+        for i in range(Bq):
+            idx = np.nonzero((s[i] >= thr[i]) & np.isfinite(s[i]))[0]
+            cand_s[i].append(s[i, idx])
+            cand_r[i].append(idx.astype(np.int64) + lo)
+    out_s = np.full((Bq, k), -np.inf, dtype=np.float32)
+    out_r = np.full((Bq, k), -1, dtype=np.int64)
+    for i in range(Bq):
+        cs = np.concatenate(cand_s[i]) if cand_s[i] else np.zeros(0, np.float32)
+        cr = np.concatenate(cand_r[i]) if cand_r[i] else np.zeros(0, np.int64)
+        order = np.lexsort((cr, -cs))[:k]
+        out_s[i, :len(order)] = cs[order]
+        out_r[i, :len(order)] = cr[order] + row0
+    return out_s, out_r
+
+
 def cosine_topk_fast(q, g_unit, k):
     """Timing-oriented variant for the CPU baseline: g_unit is already unit float32 (as a
     server would keep it); one BLAS product per chunk, argpartition, then an exact sort of

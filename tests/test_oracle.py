@@ -247,3 +247,33 @@ def test_oracle_fixtures_unchanged():
     s, r = osr.cosine_topk(z["q"], z["g"].astype(np.float32), 5, keys=z["keys"], qkeys=z["qkeys"],
                            gallery_dtype=np.float16)
     assert np.array_equal(r, z["rows"]) or np.abs(s - z["scores"]).max() < 1e-3
+
+
+def test_topk_stored_equals_cosine_topk():
+    """The large-gallery form of the search oracle (stored fp16 rows scored as they stand, only the
+    rows at or above a chunk's k-th best kept) gives the answer of the plain form: keys, ANY,
+    tombstones, a key nobody has, exact ties across chunks, fewer rows than k."""
+    from frhot import synth
+    rng = np.random.default_rng(0)
+    n, d = 150_000, 64
+    g = synth.unit_gallery(1, n, d)
+    g[140_000] = g[5]
+    g[70_000] = g[5]
+    keys = rng.integers(0, 3, n).astype(np.int32)
+    keys[::50] = -1
+    t = rng.integers(0, n, 40)
+    q = synth.planted_queries(rng, g[t], 0.7)
+    q[0] = g[5]
+    qk = keys[t].copy()
+    qk[::4] = -2
+    qk[3] = 77
+    q16 = osr.unit_rows(q).astype(np.float16)
+    g16 = osr.unit_rows(g).astype(np.float16)
+    for k, kw in ((10, dict(keys=keys, qkeys=qk)), (5, {})):
+        a_s, a_r = osr.cosine_topk(q, g, k, gallery_dtype=np.float16, **kw)
+        b_s, b_r = osr.topk_stored(q16, g16, k, **kw)
+        assert np.array_equal(a_r, b_r)
+        assert np.array_equal(a_s, b_s)
+    assert list(b_r[0, :3]) == [5, 70_000, 140_000]
+    s, r = osr.topk_stored(q16[:2], g16[:3], 5, row0=100)
+    assert (r[:, 3:] == -1).all() and np.isneginf(s[:, 3:]).all() and sorted(r[0, :3]) == [100, 101, 102]
