@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,6 +30,20 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// No exception may cross the C ABI: every extern "C" body runs inside guarded().
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(FRHOT_ECAPACITY, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(FRHOT_EHIP, "unexpected failure: %s", e.what());
+    } catch (...) {
+        return fail(FRHOT_EHIP, "unexpected failure");
+    }
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -137,6 +153,10 @@ struct frhot_gallery {
     float* up_vecs = nullptr; int32_t* up_keys = nullptr; int64_t* up_rows = nullptr; int up_cap = 0;
     void* q16 = nullptr; float* q32 = nullptr; int32_t* qk = nullptr; float* out_s = nullptr; int64_t* out_r = nullptr;
     int q_cap = 0;
+    // staging of tombstone / read / write_f16 (rows, keys, fp16 rows), grown on demand and kept
+    // while small, so that enrol / evict / delete calls allocate nothing
+    int64_t* mut_rows = nullptr; int32_t* mut_keys = nullptr; void* mut_f16 = nullptr;
+    size_t mut_cap = 0, mut_f16_cap = 0;
 };
 
 namespace {
@@ -273,12 +293,25 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
             for (size_t y = 0; y < h; ++y) memcpy(dst + y * row, crops[i] + y * (size_t)strides[i], row);
         }
     };
-    std::vector<std::thread> workers;
-    for (int t = 1; t < nthr; ++t) workers.emplace_back(pack, first[t], first[t + 1]);
+    // Workers are joined on every way out of this function (a thread that is still joinable when
+    // its std::thread is destroyed ends the process); a range whose thread cannot be started
+    // (process thread limit) is packed by the calling thread instead.
+    struct Joiner {
+        std::vector<std::thread> t;
+        ~Joiner() { for (auto& w : t) if (w.joinable()) w.join(); }
+    } pool;
+    pool.t.resize(nthr > 1 ? nthr - 1 : 0);
+    for (int t = 1; t < nthr; ++t) {
+        try {
+            pool.t[t - 1] = std::thread(pack, first[t], first[t + 1]);
+        } catch (const std::system_error&) {
+            pack(first[t], first[t + 1]);
+        }
+    }
     pack(first[0], first[1]);
     hipError_t err = hipSuccess;
     for (int t = 0; t < nthr; ++t) {
-        if (t > 0) workers[t - 1].join();               // every thread is joined, also after a failed copy
+        if (t > 0 && pool.t[t - 1].joinable()) pool.t[t - 1].join();   // every thread is joined, also after a failed copy
         if (err != hipSuccess || first[t] >= first[t + 1]) continue;
         const size_t lo = (size_t)offsets[first[t]];
         const size_t hi = first[t + 1] < B ? (size_t)offsets[first[t + 1]] : total;
@@ -338,6 +371,37 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
         g->qbound_cap = cap;
     }
     return search_launch(g, q16, qkeys_dev, Bq, k, scores_dev, rows_dev, row_base, g->part_s, g->part_r, g->qbound);
+}
+
+// Staging for n rows (and, with `with_rows`, n fp16 rows).  Buffers above kMutKeep rows are
+// released again by gallery_trim_mutation_staging after the call.
+constexpr size_t kMutKeep = 4096;
+int gallery_grow_mutation_staging(frhot_gallery* g, size_t n, bool with_rows) {
+    hipStream_t s = g->ctx->stream;
+    if (n > g->mut_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->mut_cap = 0;
+        HIP_TRY(free_null(g->mut_rows));
+        HIP_TRY(free_null(g->mut_keys));
+        const size_t cap = n < kMutKeep ? (n + n / 2 + 16 < kMutKeep ? n + n / 2 + 16 : kMutKeep) : n;
+        HIP_TRY(hipMalloc((void**)&g->mut_rows, cap * 8));
+        HIP_TRY(hipMalloc((void**)&g->mut_keys, cap * 4));
+        g->mut_cap = cap;
+    }
+    if (with_rows && n > g->mut_f16_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->mut_f16_cap = 0;
+        HIP_TRY(free_null(g->mut_f16));
+        const size_t cap = n < kMutKeep ? (n + n / 2 + 16 < kMutKeep ? n + n / 2 + 16 : kMutKeep) : n;
+        HIP_TRY(hipMalloc(&g->mut_f16, cap * (size_t)g->D * 2));
+        g->mut_f16_cap = cap;
+    }
+    return FRHOT_OK;
+}
+
+void gallery_trim_mutation_staging(frhot_gallery* g) {
+    if (g->mut_cap > kMutKeep) { g->mut_cap = 0; (void)free_null(g->mut_rows); (void)free_null(g->mut_keys); }
+    if (g->mut_f16_cap > kMutKeep) { g->mut_f16_cap = 0; (void)free_null(g->mut_f16); }
 }
 
 int gallery_grow_query_staging(frhot_gallery* g, int Bq) {
@@ -400,6 +464,7 @@ static int ctx_init(frhot_ctx* c) {
 }
 
 int frhot_ctx_create(int device_id, void* stream, int max_batch, frhot_ctx** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(FRHOT_EINVAL, "out is null");
     *out = nullptr;
     // 2048: the conv kernels address a layer's input with 32-bit byte offsets (conv3_2: 1.72 MB per face)
@@ -427,9 +492,11 @@ int frhot_ctx_create(int device_id, void* stream, int max_batch, frhot_ctx** out
     }
     *out = c;
     return FRHOT_OK;
+    });
 }
 
 int frhot_ctx_destroy(frhot_ctx* c) {
+    return guarded([&]() -> int {
     if (!c) return FRHOT_OK;
     DeviceGuard dg(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -450,16 +517,20 @@ int frhot_ctx_destroy(frhot_ctx* c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FRHOT_OK;
+    });
 }
 
 int frhot_ctx_sync(frhot_ctx* c) {
+    return guarded([&]() -> int {
     if (!c) return fail(FRHOT_EINVAL, "ctx is null");
     DeviceGuard dg(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FRHOT_OK;
+    });
 }
 
 int frhot_model_load(frhot_ctx* c, const void* blob_v, size_t nbytes, float input_scale) {
+    return guarded([&]() -> int {
     if (!c || !blob_v) return fail(FRHOT_EINVAL, "null argument");
     if (!(input_scale > 0.f) || !std::isfinite(input_scale)) return fail(FRHOT_EINVAL, "input_scale must be positive");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -518,19 +589,23 @@ int frhot_model_load(frhot_ctx* c, const void* blob_v, size_t nbytes, float inpu
     c->input_scale = input_scale;
     c->model = true;
     return FRHOT_OK;
+    });
 }
 
 int frhot_embed_dev(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
                     const int32_t* strides, int B, unsigned flags, void* out_f32_dev, void* out_q_f16_dev, int Dq) {
+    return guarded([&]() -> int {
     if (!c) return fail(FRHOT_EINVAL, "ctx is null");
     if (!out_f32_dev && !out_q_f16_dev) return fail(FRHOT_EINVAL, "no output requested");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
     return embed_enqueue(c, crops_dev, offsets, hw, strides, B, flags, (float*)out_f32_dev, out_q_f16_dev, Dq);
+    });
 }
 
 int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, const int32_t* strides, int B,
                 unsigned flags, float* out) {
+    return guarded([&]() -> int {
     if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
     if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
     std::lock_guard<std::mutex> lk(c->mu);
@@ -543,9 +618,11 @@ int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     HIP_TRY(hipMemcpyAsync(out, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FRHOT_OK;
+    });
 }
 
 int frhot_debug_read(frhot_ctx* c, int stage, int B, void* host_out, size_t nbytes) {
+    return guarded([&]() -> int {
     if (!c || !host_out) return fail(FRHOT_EINVAL, "null argument");
     if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
     std::lock_guard<std::mutex> lk(c->mu);
@@ -560,9 +637,11 @@ int frhot_debug_read(frhot_ctx* c, int stage, int B, void* host_out, size_t nbyt
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(host_out, src, need, hipMemcpyDeviceToHost));
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_create(frhot_ctx* c, int D, int64_t capacity, frhot_gallery** out) {
+    return guarded([&]() -> int {
     if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
     *out = nullptr;
     if (D < 64 || D % 64 || D > 8192) return fail(FRHOT_EINVAL, "D %d must be a multiple of 64 in 64..8192", D);
@@ -584,23 +663,27 @@ int frhot_gallery_create(frhot_ctx* c, int D, int64_t capacity, frhot_gallery** 
     }
     *out = g;
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_destroy(frhot_gallery* g) {
+    return guarded([&]() -> int {
     if (!g) return FRHOT_OK;
     std::lock_guard<std::mutex> lk(g->ctx->mu);
     DeviceGuard dg(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->rows, g->keys, g->part_s, g->part_r, g->qbound, g->up_vecs, g->up_keys, g->up_rows,
-                    g->q16, g->q32, g->qk, g->out_s, g->out_r};
+                    g->q16, g->q32, g->qk, g->out_s, g->out_r, g->mut_rows, g->mut_keys, g->mut_f16};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete g;
     return FRHOT_OK;
+    });
 }
 
 int64_t frhot_gallery_rows(frhot_gallery* g) { return g ? g->nrows : 0; }
 
 int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* keys, const int64_t* rows, int n) {
+    return guarded([&]() -> int {
     if (!g || !vecs || !keys || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
     int64_t hi = -1;
@@ -639,9 +722,11 @@ int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* key
     if (!(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
     if (hi + 1 > g->nrows) g->nrows = hi + 1;
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n) {
+    return guarded([&]() -> int {
     if (!g || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
     for (int i = 0; i < n; ++i)
@@ -649,18 +734,20 @@ int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n) {
     frhot_ctx* c = g->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
-    int64_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8));
-    hipError_t e = hipMemcpyAsync(d, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_gallery_set_keys(d, n, FRHOT_KEY_DEAD, g->keys, c->stream);
+    int rc = gallery_grow_mutation_staging(g, (size_t)n, false);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(g->mut_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_set_keys(g->mut_rows, n, FRHOT_KEY_DEAD, g->keys, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    gallery_trim_mutation_staging(g);
     if (e != hipSuccess) return fail(FRHOT_EHIP, "tombstone failed: %s", hipGetErrorString(e));
     g->dense = false;
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, int64_t n, int nkeys, int dup_every) {
+    return guarded([&]() -> int {
     if (!g) return fail(FRHOT_EINVAL, "gallery is null");
     if (row0 < 0 || n <= 0 || row0 + n > g->capacity) return fail(FRHOT_ECAPACITY, "rows [%lld,%lld) outside capacity %lld", (long long)row0, (long long)(row0 + n), (long long)g->capacity);
     if (nkeys < 0 || dup_every < 0 || dup_every == 1) return fail(FRHOT_EINVAL, "bad nkeys / dup_every");
@@ -672,9 +759,11 @@ int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, 
     if (row0 > g->nrows) g->dense = false;
     if (row0 + n > g->nrows) g->nrows = row0 + n;
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f16, int32_t* out_keys) {
+    return guarded([&]() -> int {
     if (!g || !rows || !out_f16) return fail(FRHOT_EINVAL, "null argument");
     if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
     for (int i = 0; i < n; ++i)
@@ -682,23 +771,21 @@ int frhot_gallery_read(frhot_gallery* g, const int64_t* rows, int n, void* out_f
     frhot_ctx* c = g->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
-    int64_t* drows = nullptr; void* dout = nullptr; int32_t* dk = nullptr;
-    hipError_t e = hipMalloc((void**)&drows, (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * g->D * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&dk, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(drows, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_gallery_gather(g->rows, g->keys, drows, n, g->D, dout, dk, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_f16, dout, (size_t)n * g->D * 2, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && out_keys) e = hipMemcpyAsync(out_keys, dk, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    int rc = gallery_grow_mutation_staging(g, (size_t)n, true);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(g->mut_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_gather(g->rows, g->keys, g->mut_rows, n, g->D, g->mut_f16, g->mut_keys, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_f16, g->mut_f16, (size_t)n * g->D * 2, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && out_keys) e = hipMemcpyAsync(out_keys, g->mut_keys, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (drows) (void)hipFree(drows);
-    if (dout) (void)hipFree(dout);
-    if (dk) (void)hipFree(dk);
+    gallery_trim_mutation_staging(g);
     if (e != hipSuccess) return fail(FRHOT_EHIP, "gallery read failed: %s", hipGetErrorString(e));
     return FRHOT_OK;
+    });
 }
 
 int frhot_gallery_write_f16(frhot_gallery* g, const void* rows_f16, const int32_t* keys, const int64_t* rows, int n) {
+    return guarded([&]() -> int {
     if (!g || !rows_f16 || !keys || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (n <= 0) return fail(FRHOT_EINVAL, "n must be positive");
     int64_t hi = -1;
@@ -715,34 +802,34 @@ int frhot_gallery_write_f16(frhot_gallery* g, const void* rows_f16, const int32_
     frhot_ctx* c = g->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
-    void* din = nullptr; int32_t* dk = nullptr; int64_t* dr = nullptr;
-    hipError_t e = hipMalloc(&din, (size_t)n * g->D * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&dk, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)n * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(din, rows_f16, (size_t)n * g->D * 2, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dk, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dr, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = launch_gallery_scatter(din, dk, dr, n, g->D, g->rows, g->keys, c->stream);
+    int rc = gallery_grow_mutation_staging(g, (size_t)n, true);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(g->mut_f16, rows_f16, (size_t)n * g->D * 2, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->mut_keys, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->mut_rows, rows, (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_gallery_scatter(g->mut_f16, g->mut_keys, g->mut_rows, n, g->D, g->rows, g->keys, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (din) (void)hipFree(din);
-    if (dk) (void)hipFree(dk);
-    if (dr) (void)hipFree(dr);
+    gallery_trim_mutation_staging(g);
     if (e != hipSuccess) return fail(FRHOT_EHIP, "gallery write failed: %s", hipGetErrorString(e));
     if (any_dead || !(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
     if (hi + 1 > g->nrows) g->nrows = hi + 1;
     return FRHOT_OK;
+    });
 }
 
 int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev, int Bq, int k,
                      void* scores_dev, void* rows_dev, int64_t row_base) {
+    return guarded([&]() -> int {
     if (!g) return fail(FRHOT_EINVAL, "gallery is null");
     std::lock_guard<std::mutex> lk(g->ctx->mu);
     DeviceGuard dg(g->ctx->device);
     return search_enqueue(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base);
+    });
 }
 
 int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev, int Bq, int k,
                             void* scores_dev, void* rows_dev, int64_t row_base) {
+    return guarded([&]() -> int {
     if (!g) return fail(FRHOT_EINVAL, "gallery is null");
     if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
     if (!q_f16_dev || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null search arguments");
@@ -760,14 +847,20 @@ int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32
     if (g->nrows == 0) return search_fill_empty(c->stream, Bq, k, (float*)scores_dev, (int64_t*)rows_dev);
     return search_launch(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base, sc.part_s,
                          sc.part_r, sc.qbound);
+    });
 }
 
 int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq, int k, float* scores, int64_t* rows) {
+    return guarded([&]() -> int {
     if (!g || !q || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
     frhot_ctx* c = g->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
+    if (qkeys)
+        for (int i = 0; i < Bq; ++i)
+            if (qkeys[i] < 0 && qkeys[i] != FRHOT_KEY_ANY)
+                return fail(FRHOT_EINVAL, "query key %d of query %d is neither a row key nor FRHOT_KEY_ANY", qkeys[i], i);
     int rc = gallery_grow_query_staging(g, Bq);
     if (rc) return rc;
     hipStream_t s = c->stream;
@@ -780,10 +873,12 @@ int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq,
     HIP_TRY(hipMemcpyAsync(rows, g->out_r, (size_t)Bq * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return FRHOT_OK;
+    });
 }
 
 int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_dev, int P, int Bq, int k,
                          void* out_scores_dev, void* out_rows_dev) {
+    return guarded([&]() -> int {
     if (!c || !scores_dev || !rows_dev || !out_scores_dev || !out_rows_dev) return fail(FRHOT_EINVAL, "null argument");
     if (P <= 0 || P > 256 || Bq <= 0 || k <= 0 || k > 16)
         return fail(FRHOT_EINVAL, "P %d / Bq %d / k %d out of range (P <= 256, k <= 16)", P, Bq, k);
@@ -792,16 +887,22 @@ int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_
     HIP_TRY(launch_topk_final((const float*)scores_dev, (const int64_t*)rows_dev, P, k, Bq, k, 0,
                               (float*)out_scores_dev, (int64_t*)out_rows_dev, c->stream));
     return FRHOT_OK;
+    });
 }
 
 int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
                     const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
                     float* scores, int64_t* rows) {
+    return guarded([&]() -> int {
     if (!c || !g || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (g->ctx != c) return fail(FRHOT_EINVAL, "gallery belongs to another context");
     if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
     if (k <= 0 || k > 16) return fail(FRHOT_EINVAL, "k %d out of range (k <= 16)", k);
     if (g->D > kFcN) return fail(FRHOT_EINVAL, "gallery dimension %d exceeds the descriptor length", g->D);
+    if (qkeys)
+        for (int i = 0; i < B; ++i)
+            if (qkeys[i] < 0 && qkeys[i] != FRHOT_KEY_ANY)
+                return fail(FRHOT_EINVAL, "query key %d of crop %d is neither a row key nor FRHOT_KEY_ANY", qkeys[i], i);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
     std::vector<int64_t> offsets; std::vector<int32_t> ps;
@@ -818,9 +919,11 @@ int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops,
     HIP_TRY(hipMemcpyAsync(rows, c->res_r, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return FRHOT_OK;
+    });
 }
 
 int frhot_ctx_timing(frhot_ctx* c, int enable) {
+    return guarded([&]() -> int {
     if (!c) return fail(FRHOT_EINVAL, "ctx is null");
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
@@ -834,9 +937,11 @@ int frhot_ctx_timing(frhot_ctx* c, int enable) {
     for (long& n : c->ev_n) n = 0;
     c->timing = enable != 0;
     return FRHOT_OK;
+    });
 }
 
 int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
+    return guarded([&]() -> int {
     if (!c || !ms5) return fail(FRHOT_EINVAL, "null argument");
     if (!c->timing) return fail(FRHOT_ESTATE, "timing is not enabled");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -853,6 +958,7 @@ int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
         ms5[i] = n > 0 ? (float)(sum / (double)n) : 0.f;
     }
     return FRHOT_OK;
+    });
 }
 
 }  // extern "C"

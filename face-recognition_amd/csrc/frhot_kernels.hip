@@ -1524,7 +1524,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #pragma unroll
                     for (int y = 0; y < NY; ++y) {
                         __builtin_amdgcn_sched_barrier(0);
-                        const unsigned kx = mykey[y] == -2 ? 0u : (unsigned)mykey[y];
+                        // any other negative query key (the tombstone value included) is no row key:
+                        // it is compared with a value that no stored key takes, so it matches nothing
+                        const unsigned kx = mykey[y] == -2 ? 0u : (mykey[y] < 0 ? 0x80000000u : (unsigned)mykey[y]);
                         const unsigned km = mykey[y] == -2 ? 0x7fffffffu : 0u;
 #pragma unroll
                         for (int x = 0; x < NX; ++x) {

@@ -73,6 +73,28 @@ class _MicroBatcher:
                         fut.set_exception(e)
 
 
+MAX_CROP_SIDE = 16384     # frhot_embed refuses larger crops
+
+
+def crop_problem(crop) -> str | None:
+    """Why frhot_embed would refuse this crop (None: it is usable).  Mirrors the library's own
+    checks so that a bad crop fails its own request instead of the whole device batch:
+    uint8 [h, w, 3], sides within 1..16384, and an aspect fit into 224 x 224 that keeps at
+    least one row and one column (DeepFace's resize: dsize = int(side * min(224/h, 224/w)))."""
+    a = np.asarray(crop)
+    if a.ndim != 3 or a.shape[2] != 3:
+        return f"crop must have shape [h, w, 3], not {a.shape}"
+    if a.dtype != np.uint8:
+        return f"crop must be uint8, not {a.dtype}"
+    h, w = a.shape[:2]
+    if not (1 <= h <= MAX_CROP_SIDE and 1 <= w <= MAX_CROP_SIDE):
+        return f"crop sides {h} x {w} outside 1..{MAX_CROP_SIDE}"
+    f = min(224.0 / h, 224.0 / w)
+    if int(w * f) < 1 or int(h * f) < 1:
+        return f"crop {h} x {w} resizes to an empty image"
+    return None
+
+
 class EmbedBatcher(_MicroBatcher):
     """Groups concurrent single-crop embeds into one frhot_embed per gamma setting."""
 
@@ -82,6 +104,11 @@ class EmbedBatcher(_MicroBatcher):
 
     def submit(self, crop: np.ndarray, gamma: bool = False) -> Future:
         """Queue one uint8 BGR crop; the future resolves to its float32 [4096] unit descriptor."""
+        bad = crop_problem(crop)
+        if bad is not None:             # fails this request only, before it can join a batch
+            fut: Future = Future()
+            fut.set_exception(ValueError(bad))
+            return fut
         return self._put((crop, bool(gamma)))
 
     def embed(self, crop: np.ndarray, gamma: bool = False, timeout: float | None = 60.0) -> np.ndarray:
@@ -97,10 +124,20 @@ class EmbedBatcher(_MicroBatcher):
                 out = self.ctx.embed([g[0][0] for g in group], gamma=flag)
                 for g, row in zip(group, out):
                     g[1].set_result(row.copy())
+                self.batches += 1
             except Exception as e:
-                for g in group:
-                    g[1].set_exception(e)
-            self.batches += 1
+                # the library refuses a call as a whole: find the crop(s) it refuses by embedding
+                # one at a time, so that every other request of the batch still gets its answer
+                if len(group) == 1:
+                    group[0][1].set_exception(e)
+                    self.batches += 1
+                else:
+                    for g in group:
+                        try:
+                            g[1].set_result(self.ctx.embed([g[0][0]], gamma=flag)[0].copy())
+                        except Exception as e1:
+                            g[1].set_exception(e1)
+                        self.batches += 1
             self.items += len(group)
 
 

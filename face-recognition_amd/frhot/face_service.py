@@ -31,23 +31,38 @@ PROCESSING_SEMAPHORE_LIMIT = 10  # face_service.py:43
 
 
 def decode_image(img_base64: str) -> np.ndarray:
-    """base64 -> uint8 HxWx3 BGR (the reference uses cv2.imdecode(flags=-1), face_service.py:65-66)."""
+    """base64 -> pixel array, shaped as cv2.imdecode(flags=-1) shapes it (face_service.py:65-66):
+    colour -> uint8 [h,w,3] BGR; colour or grey with alpha -> [h,w,4] BGRA; grey -> [h,w];
+    16-bit grey -> uint16 [h,w] (the caller's astype('uint8') wraps it, as in the reference).
+    The decoder is PIL (cv2 is not a dependency of this package): JPEG IDCT and chroma
+    upsampling may differ from OpenCV's libjpeg build by a few levels per pixel, and 16-bit
+    colour files come out as 8-bit.  Hosts that have cv2 pass their own decoder to FaceService."""
     from PIL import Image
     contents = base64.b64decode(img_base64)
     img = Image.open(io.BytesIO(contents))
     img.load()
-    if img.mode not in ("RGB", "RGBA", "L"):
-        img = img.convert("RGB")
+    if img.mode in ("I;16", "I;16B", "I;16L", "I"):
+        return np.asarray(img).astype(np.uint16)
+    if img.mode in ("LA", "PA") or (img.mode == "P" and "transparency" in img.info):
+        img = img.convert("RGBA")
+    elif img.mode not in ("RGB", "RGBA", "L"):
+        img = img.convert("L" if img.mode == "1" else "RGB")
     arr = np.asarray(img)
     if arr.ndim == 2:
         return arr
-    return np.ascontiguousarray(arr[:, :, :3][:, :, ::-1])
+    if arr.shape[2] == 4:
+        return np.ascontiguousarray(arr[:, :, [2, 1, 0, 3]])
+    return np.ascontiguousarray(arr[:, :, ::-1])
 
 
 class FaceService:
-    def __init__(self, database_client, image_sink=None):
+    def __init__(self, database_client, image_sink=None, decoder=None):
+        """`decoder`: base64 string -> pixel array; default decode_image (PIL).  A host with OpenCV
+        passes `lambda b: cv2.imdecode(np.frombuffer(base64.b64decode(b), np.uint8), -1)` to decode
+        exactly as the reference does."""
         self.database_client = database_client
         self.image_sink = image_sink
+        self.decoder = decoder or decode_image
         self._http_sem = None
         self._proc_sem = None
         self._pool = ThreadPoolExecutor(max_workers=PROCESSING_SEMAPHORE_LIMIT, thread_name_prefix="frhot-embed")
@@ -68,7 +83,7 @@ class FaceService:
         _, proc = self._sems()
         async with proc:
             try:
-                img_decode = decode_image(data.img_base64)
+                img_decode = self.decoder(data.img_base64)
                 img_size = img_decode.shape
                 boxes = [[0, 0, img_size[1], img_size[0]]]     # face_service.py:128-131
                 distances = [50]

@@ -144,7 +144,11 @@ class GalleryService:
                     self.gallery.upsert(vec, self._key(collection_name, old["payload"].get("store_id")), [row])
                     return 201, {"message": "Point inserted"}
                 row = self._alloc_row()
-                self.gallery.upsert(vec, self._key(collection_name, store_id), [row])
+                try:
+                    self.gallery.upsert(vec, self._key(collection_name, store_id), [row])
+                except Exception:
+                    self._free.append(row)          # the row was never written: hand it back
+                    raise
                 self._seq += 1
                 self._points[row] = {"uid": str(uuid.uuid4()), "payload": payload, "collection": collection_name,
                                      "seq": self._seq}
@@ -274,14 +278,39 @@ class GalleryService:
             if len(points) != vec.shape[0]:
                 return 404, {"message": "snapshot is inconsistent"}
             with self._lock:
-                self._collections.setdefault(collection_name, None)
-                self._drop_rows([r for r, p in self._points.items() if p["collection"] == collection_name])
+                # The snapshot's rows are written to fresh rows FIRST and the collection's current
+                # points dropped only after that succeeded: a snapshot that does not fit, or a
+                # failing device write, leaves the live collection as it was and leaks no row.
+                old_rows = [r for r, p in self._points.items() if p["collection"] == collection_name]
+                room = len(self._free) + (self.capacity - self._next_row)
+                if len(points) > room + len(old_rows):
+                    return 404, {"message": f"snapshot holds {len(points)} points, the gallery has room for "
+                                            f"{room + len(old_rows)}"}
+                if len(points) > room:
+                    # it only fits in the rows the collection occupies now: those go first, and a
+                    # failing write then leaves the collection empty (its rows are handed back)
+                    self._drop_rows(old_rows)
+                    old_rows = []
+                existed = collection_name in self._collections
                 rows, keys = [], []
-                for pt in points:
-                    rows.append(self._alloc_row())
-                    keys.append(self._key(collection_name, pt["payload"].get("store_id")))
-                if rows:
-                    self.gallery.write_f16(vec, np.asarray(keys, np.int32), np.asarray(rows, np.int64))
+                try:
+                    for pt in points:
+                        rows.append(self._alloc_row())
+                        keys.append(self._key(collection_name, pt["payload"].get("store_id")))
+                    if rows:
+                        self.gallery.write_f16(vec, np.asarray(keys, np.int32), np.asarray(rows, np.int64))
+                except Exception:
+                    self._free.extend(rows)
+                    if rows:
+                        try:        # whatever part of the write landed must not answer searches
+                            self.gallery.tombstone(np.asarray(rows, dtype=np.int64))
+                        except Exception:
+                            pass
+                    if not existed:
+                        self._collections.pop(collection_name, None)
+                    raise
+                self._collections.setdefault(collection_name, None)
+                self._drop_rows(old_rows)
                 for r, pt in zip(rows, points):
                     self._seq = max(self._seq, int(pt["seq"]))
                     self._points[r] = {"uid": pt["uid"], "payload": pt["payload"], "collection": collection_name,

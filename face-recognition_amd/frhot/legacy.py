@@ -31,8 +31,10 @@ def get_embedding(imgf, imgf_real=None):
     if imgf.ndim != 3:
         # DeepFace.represent(detector_backend="skip") raises for non-3-dimensional input
         raise ValueError(f"Input img must be 3 dimensional but it is {imgf.shape}")
-    if imgf.shape[2] == 4:
-        imgf = imgf[:, :, :3]
+    if imgf.shape[2] != 3:
+        # a 4-channel crop (cv2.imdecode(flags=-1) of an RGBA file) reaches the Keras model as
+        # [1,224,224,4] in the reference and fails there: same outcome, the caller answers 500
+        raise ValueError(f"Input img must have 3 channels but it is {imgf.shape}")
     emb = _engine.embed(np.ascontiguousarray(imgf, dtype=np.uint8), gamma=False)
     return [float(v) for v in emb], True
 

@@ -43,7 +43,7 @@ extern "C" {
 
 /* query keys */
 #define FRHOT_KEY_ANY       (-2)  /* query matches every live row */
-#define FRHOT_KEY_DEAD      (-1)  /* row key of a tombstoned row */
+#define FRHOT_KEY_DEAD      (-1)  /* row key of a tombstoned row; as a query key it matches nothing */
 
 typedef struct frhot_ctx frhot_ctx;
 typedef struct frhot_gallery frhot_gallery;
@@ -162,7 +162,8 @@ int64_t frhot_gallery_rows(frhot_gallery* g);
 
 /*
  * Exact cosine top-k of Bq queries against every live row whose key matches
- * qkeys[i] (FRHOT_KEY_ANY: all live rows; qkeys NULL: ANY for all).  `q` is
+ * qkeys[i] (FRHOT_KEY_ANY: all live rows; qkeys NULL: ANY for all; any other negative
+ * key: FRHOT_EINVAL here and in frhot_recognise, an empty answer in the *_dev forms).  `q` is
  * [Bq,D] float32 on the host (normalised inside).  scores [Bq,k] float32
  * descending, rows [Bq,k] int64 (-1 and score -inf where fewer than k rows
  * match).  Ties in score are ordered by ascending row.

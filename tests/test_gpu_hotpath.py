@@ -323,6 +323,38 @@ def test_search_key_filter_and_tombstones(gpu_ctx):
     gal.close()
 
 
+def test_dead_key_as_query_key_matches_nothing(gpu_ctx):
+    """A query key of -1 (the tombstone value) or any other negative key but ANY is no row key:
+    the host forms refuse it, the device-pointer form answers with no row at all, so deleted
+    faces can never come back through it."""
+    import torch
+    from frhot import FrhotError, synth
+    from frhot.engine import Gallery
+    n, d = 3000, 64
+    g = synth.unit_gallery(seed=12, n=n, d=d)
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, (np.arange(n) % 4).astype(np.int32), np.arange(n))
+    gal.tombstone(np.arange(0, n, 3))
+    with pytest.raises(FrhotError):
+        gal.search(g[:4], np.array([0, -1, 1, 2], np.int32), 5)
+    with pytest.raises(FrhotError):
+        gal.search(g[:4], np.array([0, 1, -7, 2], np.int32), 5)
+    dev = torch.device("cuda", 0)
+    q16 = torch.from_numpy(g[:6].astype(np.float16)).to(dev)
+    qk = torch.tensor([-1, -2, 1, -5, -2147483648, 0], dtype=torch.int32, device=dev)
+    s = torch.empty((6, 5), dtype=torch.float32, device=dev)
+    r = torch.empty((6, 5), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    gal.search_dev(q16.data_ptr(), qk.data_ptr(), 6, 5, s.data_ptr(), r.data_ptr(), 0)
+    gpu_ctx.sync()
+    r, s = r.cpu().numpy(), s.cpu().numpy()
+    for i in (0, 3, 4):
+        assert (r[i] == -1).all() and np.isneginf(s[i]).all()
+    assert r[1, 0] == 1 and r[2, 0] == 1                 # row 1 is live with key 1; ANY finds it too
+    assert (r[5] % 3 != 0).all() and (r[5] % 4 == 0).all()    # row 0 is dead: live rows of key 0 only
+    gal.close()
+
+
 def test_synthetic_fill_bit_exact(gpu_ctx):
     from frhot.engine import Gallery
     from oracle import synth_gallery as sg

@@ -410,3 +410,111 @@ def test_keras_h5_converter_layout(monkeypatch):
     ours = F.conv2d(x, torch.from_numpy(out["conv1_2.w"]).permute(0, 3, 1, 2), padding=1)               # KRSC -> OIHW
     assert torch.equal(keras, ours)
     assert pack_blob(out).size > 268_000_000
+
+
+# ------------------------------------------- failure isolation (host side) ---
+def test_one_bad_crop_fails_only_its_own_request():
+    """A crop the library would refuse (wrong channel count, a strip that resizes to nothing) fails
+    at submit(), alone; a refusal that only the device call reports makes the batch go out again
+    crop by crop, so the other requests of the group still get their answers."""
+    from frhot.batcher import EmbedBatcher, crop_problem
+
+    class Ctx:
+        max_batch = 8
+        calls = []
+
+        def embed(self, images, gamma=False):
+            self.calls.append(len(images))
+            if any(im[0, 0, 0] == 13 for im in images):
+                raise RuntimeError("frhot error -1: bad crop")
+            return np.stack([np.full(4096, float(im[0, 0, 0]), np.float32) for im in images])
+
+    assert crop_problem(np.zeros((1, 300, 3), np.uint8)) is not None          # int(1 * 224/300) == 0
+    assert crop_problem(np.zeros((300, 1, 3), np.uint8)) is not None
+    assert crop_problem(np.zeros((5, 5, 4), np.uint8)) is not None
+    assert crop_problem(np.zeros((5, 5), np.uint8)) is not None
+    assert crop_problem(np.zeros((5, 5, 3), np.float32)) is not None
+    assert crop_problem(np.zeros((1, 224, 3), np.uint8)) is None
+    ctx = Ctx()
+    b = EmbedBatcher(ctx, max_delay_s=0.2)
+    crops = [np.full((4, 4, 3), i, np.uint8) for i in range(6)]
+    crops[2] = np.zeros((1, 300, 3), np.uint8)         # refused at submit
+    crops[4] = np.full((4, 4, 3), 13, np.uint8)        # refused by the device call only
+    futs = [b.submit(c) for c in crops]
+    res = []
+    for f in futs:
+        try:
+            res.append(f.result(timeout=10)[0])
+        except Exception as e:
+            res.append(type(e).__name__)
+    b.close()
+    assert res == [0.0, 1.0, "ValueError", 3.0, "RuntimeError", 5.0]
+    assert ctx.calls[0] == 5 and sorted(ctx.calls[1:]) == [1, 1, 1, 1, 1]
+
+
+def _b64_pil(img, mode=None, fmt="PNG"):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img, mode=mode).save(buf, format=fmt)
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+def test_decoder_shapes_and_channel_outcomes(client):
+    """decode_image shapes its output as cv2.imdecode(flags=-1) does; what the reference cannot embed
+    (4 channels, grey) ends in its 500 branch (face_service.py:246-253), also here."""
+    from frhot.face_service import FaceService, decode_image
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 255, size=(40, 30, 3), dtype=np.uint8)
+    rgba = np.dstack([rgb, np.full((40, 30), 200, np.uint8)])
+    grey = rgb[:, :, 0]
+    g16 = (grey.astype(np.uint16) * 257)
+    d = decode_image(_b64_pil(rgb))
+    assert d.shape == (40, 30, 3) and np.array_equal(d, rgb[:, :, ::-1])
+    d = decode_image(_b64_pil(rgba))
+    assert d.shape == (40, 30, 4) and np.array_equal(d[:, :, :3], rgb[:, :, ::-1]) and (d[:, :, 3] == 200).all()
+    assert decode_image(_b64_pil(grey)).shape == (40, 30)
+    d = decode_image(_b64_pil(g16))
+    assert d.dtype == np.uint16 and np.array_equal(d, g16)
+    H = {"X-API-Key": "k"}
+    for img in (_b64_pil(rgba), _b64_pil(grey), _b64_pil(g16)):
+        r = client.post("/face_recog_img_base64", json={"img_base64": img, "role": "1", "store_id": "T"}, headers=H)
+        assert r.status_code == 500 and r.json() == {"status": 2, "message": "Error! Please try again"}
+    # an injected decoder replaces PIL
+    seen = []
+    svc = FaceService(None, decoder=lambda b: seen.append(b) or rgb)
+    assert svc.decoder("xyz") is rgb and seen == ["xyz"]
+
+
+def test_failed_writes_leak_no_rows_and_keep_the_live_collection(tmp_path):
+    """insert_point hands its row back when the device write fails; recover_snapshot writes the
+    snapshot before it drops anything, so a failing write leaves the collection answering."""
+    svc = _service(8, 16)
+    svc.create_collection("S_Employees")
+    rng = np.random.default_rng(5)
+    vecs = rng.normal(size=(6, 8)).astype(np.float32)
+    for i in range(6):
+        assert svc.insert_point("S_Employees", vecs[i], f"p{i}", f"n{i}", "S")[0] == 201
+    st, info = svc.create_snapshot("S_Employees", str(tmp_path))
+    path = str(tmp_path / "S_Employees" / info["name"])
+    before = [svc.search_point("S_Employees", vecs[i], "S") for i in range(6)]
+    real_upsert, real_write = svc.gallery.upsert, svc.gallery.write_f16
+
+    def boom(*a, **k):
+        raise RuntimeError("device write failed")
+
+    svc.gallery.upsert = boom
+    free0, next0 = len(svc._free), svc._next_row
+    assert svc.insert_point("S_Employees", vecs[0], "q", "q", "S") == (404, {"message": "device write failed"})
+    assert len(svc._free) + (svc.capacity - svc._next_row) == free0 + (svc.capacity - next0)
+    svc.gallery.upsert = real_upsert
+    svc.gallery.write_f16 = boom
+    assert svc.recover_snapshot("S_Employees", path)[0] == 404
+    assert svc.point_count("S_Employees") == 6
+    assert [svc.search_point("S_Employees", vecs[i], "S") for i in range(6)] == before
+    assert len(svc._free) + (svc.capacity - svc._next_row) == 16 - 6
+    svc.gallery.write_f16 = real_write
+    assert svc.recover_snapshot("S_Employees", path)[0] == 200
+    assert svc.point_count("S_Employees") == 6 and len(svc._free) + (svc.capacity - svc._next_row) == 10
+    # a snapshot larger than the gallery is refused before anything is dropped
+    small = _service(8, 4)
+    assert small.recover_snapshot("S_Employees", path)[0] == 404 and small.point_count("S_Employees") == 0
