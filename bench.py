@@ -46,36 +46,92 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0xFACE0000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-scan64", action="store_true", help="skip the secondary HBM-bound scan measurement")
+    ap.add_argument("--no-scan64", action="store_true", help="skip the secondary scan-only measurements")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive (host crops in) measurement")
     ap.add_argument("--cpu-faces", type=int, default=4, help="faces the CPU baseline embeds")
     ap.add_argument("--cpu-rows", type=int, default=400_000, help="gallery rows the CPU baseline scans")
     return ap.parse_args()
 
 
+def host_cpu_info():
+    """CPU model, physical cores and logical CPUs of the host, from /proc/cpuinfo."""
+    model, cores, logical = None, set(), 0
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            key, _, val = ln.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                logical += 1
+            elif key == "model name" and model is None:
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or None), (logical or os.cpu_count())
+
+
+def cpu_threads():
+    """Threads the CPU baseline may use: the share this job was given (OMP_NUM_THREADS on the GPU
+    box), else every CPU the process may run on."""
+    n = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if n > 0:
+        return n
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(ctx, gal, images, args, rows_local):
-    """Time the CPU oracle on a bounded sample of the same workload; also gate correctness."""
+    """Time the CPU oracle on a bounded sample of the same workload (all threads of this job's CPU
+    share, then one thread); also gate correctness of the GPU answer on the same sample."""
     from oracle import preprocess as op, search as osr, vggface
     from frhot.weights import synthetic_weights
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    threads = cpu_threads()
     nf = min(args.cpu_faces, len(images))
     w = synthetic_weights(seed=args.seed & 0xFFFF)
-    t0 = time.perf_counter()
-    x = np.stack([op.preprocess(im, apply_gamma=True) for im in images[:nf]])
-    ref = vggface.embed(x, w, threads=threads)
-    t_embed = (time.perf_counter() - t0) / nf
-    got = ctx.embed(images[:nf], gamma=True)
-    cos = (got.astype(np.float64) * ref).sum(1) / np.linalg.norm(got.astype(np.float64), axis=1)
-    # scan sample: the first ns rows of this rank's shard, float32 BLAS + partial sort
     ns = int(min(args.cpu_rows, rows_local))
     g16, _ = gal.read(np.arange(ns))
     g32 = g16.astype(np.float32)
-    qd = ref[:, :args.dim]
-    t0 = time.perf_counter()
-    s_ref, r_ref = osr.cosine_topk_fast(qd, g32, args.k)
-    t_scan = (time.perf_counter() - t0) / nf * (args.gallery_rows / ns)
+
+    def run(nthreads, faces):
+        torch.set_num_threads(nthreads)
+        try:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=nthreads)
+        except ImportError:
+            limit = None
+        try:
+            t0 = time.perf_counter()
+            x = np.stack([op.preprocess(im, apply_gamma=True) for im in images[:faces]])
+            ref = vggface.embed(x, w, threads=nthreads)
+            t_embed = (time.perf_counter() - t0) / faces
+            qd = ref[:, :args.dim]
+            t0 = time.perf_counter()
+            s_ref, r_ref = osr.cosine_topk_fast(qd, g32, args.k)
+            t_scan = (time.perf_counter() - t0) / faces * (args.gallery_rows / ns)
+        finally:
+            if limit is not None:
+                limit.restore_original_limits()
+        return ref, s_ref, t_embed, t_scan
+
+    ref, s_ref, t_embed, t_scan = run(threads, nf)
+    _, _, t_embed1, t_scan1 = run(1, 1)
+    torch.set_num_threads(threads)
+    got = ctx.embed(images[:nf], gamma=True)
+    cos = (got.astype(np.float64) * ref).sum(1) / np.linalg.norm(got.astype(np.float64), axis=1)
     # gate: over the full shard the GPU must return, for every sampled query, scores that are
     # the true dot products of the rows it names and no sampled row may beat its k-th score
+    qd = ref[:, :args.dim]
     qn = qd / np.linalg.norm(qd, axis=1, keepdims=True)
     s_gpu, r_gpu = gal.search(qn.astype(np.float32), None, args.k)
     rows_back, _ = gal.read(r_gpu.reshape(-1))
@@ -83,12 +139,49 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     redo = (rows_back.astype(np.float32).reshape(nf, args.k, -1) * q16[:, None, :]).sum(-1)
     ok_scores = bool(np.abs(redo - s_gpu).max() <= 1e-4)
     ok_missed = bool((s_ref[:, 0] <= s_gpu[:, 0] + 1e-4).all() and (s_ref[:, -1] <= s_gpu[:, -1] + 1e-4).all())
+    model, phys, logical = host_cpu_info()
     return {
         "value": 1.0 / (t_embed + t_scan), "unit": "faces/s", "cores": threads, "kind": "port",
         "sample": (f"oracle (torch-CPU fp32 VGG-Face + numpy f32 exact top-{args.k}) on {nf} of the bench crops; "
-                   f"scan timed on the first {ns} gallery rows and scaled to {args.gallery_rows}"),
+                   f"scan timed on the first {ns} gallery rows and scaled to {args.gallery_rows}; "
+                   f"value_1thread: one crop and the same row slice on one thread"),
         "embed_s_per_face": t_embed, "scan_s_per_face": t_scan,
+        "value_1thread": 1.0 / (t_embed1 + t_scan1), "embed_s_per_face_1thread": t_embed1,
+        "scan_s_per_face_1thread": t_scan1,
+        "threads": threads, "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
     }, {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
+
+
+def scan_only(ctx, Gallery, dev, n, d, bq, k, seed, label, bound, iters=20):
+    """One scan-only shape on a gallery of its own, timed with the library's stream events."""
+    gal = Gallery(ctx, d, n)
+    gal.fill_synthetic(seed=seed, row0=0, n=n, nkeys=0, dup_every=0)
+    rows16, _ = gal.read(np.arange(bq) * (n // bq))
+    q = torch.from_numpy(rows16).to(dev)                    # stored rows as queries: unit fp16
+    s_out = torch.empty((bq, k), dtype=torch.float32, device=dev)
+    r_out = torch.empty((bq, k), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
+    ctx.timing(True)
+    for _ in range(iters):
+        gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
+    ms = ctx.stage_ms()["scan"]
+    ctx.timing(False)
+    ok = bool((r_out[:, 0].cpu().numpy() == np.arange(bq) * (n // bq)).all())
+    gal.close()
+    nbytes = n * d * 2 + bq * d * 2
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    tf = 2.0 * bq * n * d / (ms * 1e-3) / 1e12
+    tr, src = pmc_traffic(n, d, bq, k)
+    out = {"workload": f"scan only: {n}x{d} fp16 gallery, {bq} queries, top-{k}", "bound": bound,
+           "achieved": gbs if bound == "hbm" else tf, "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS,
+           "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+           "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS,
+           "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf, "mfma_frac": tf / MFMA_PEAK_TFLOPS,
+           "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms,
+           "queries_per_s": bq / (ms * 1e-3), "top1_is_the_asked_row": ok, "label": label}
+    return out
 
 
 def pmc_traffic(rows, dim, queries, k):
@@ -108,6 +201,10 @@ def pmc_traffic(rows, dim, queries, k):
     return None, None
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')} rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     # Native libraries write to the process's stdout behind Python's back (RCCL prints a version
@@ -123,21 +220,36 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    if not torch.cuda.is_available():
+    # Rehearsal switches (never set by the driver): FRHOT_BENCH_SHARE_GPU=1 puts every rank on GPU 0
+    # and FRHOT_BENCH_BACKEND=gloo exchanges through gloo (RCCL refuses two ranks on one device):
+    # the N > 1 data path, its row bases and its merge on real kernels with one GPU.
+    share_gpu = bool(os.environ.get("FRHOT_BENCH_SHARE_GPU"))
+    backend = os.environ.get("FRHOT_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+    ndev = torch.cuda.device_count()                                  # does not initialise the GPU
+    if ndev == 0:
         raise SystemExit("bench.py needs a GPU (MI355X); none is visible")
-    dev_index = local_rank
+    dev_index = 0 if share_gpu else local_rank
+    if dev_index >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} needs GPU {dev_index}, this node shows {ndev}")
     if os.environ.get("FRHOT_BENCH_WATCHDOG_S"):      # diagnosis: say where a hung run stands, then end it
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["FRHOT_BENCH_WATCHDOG_S"]), exit=True)
+    if os.environ.get("FRHOT_BENCH_TRACE_EVERY_S"):   # diagnosis: where every rank stands, again and again
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FRHOT_BENCH_TRACE_EVERY_S"]), repeat=True)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # FRHOT_BENCH_REHEARSE_DIST=1 with one rank: a one-rank RCCL group, and the gathers and the merge of the
     # multi-rank step run anyway (what a one-GPU box can rehearse of the N > 1 path)
     rehearse = world == 1 and bool(os.environ.get("FRHOT_BENCH_REHEARSE_DIST"))
     if world > 1 or rehearse:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        log(f"init_process_group({backend}) world {world}")
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        # a rank that never arrives ends the job with an error after this long instead of hanging it
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180), **kw)
 
     from frhot import synth
     from frhot.dist import ShardedSearch, shard_rows
@@ -148,11 +260,14 @@ def main():
     row_base, rows_local = shard_rows(args.gallery_rows, P, rank)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
+        log("context + model")
         ctx = Context(device=dev_index, max_batch=B, stream=stream.cuda_stream)
         ctx.load_model(pack_blob(synthetic_weights(seed=args.seed & 0xFFFF)), input_scale=1.0 / 16.0)
+        log("crops")
         images = synth.crops(seed=args.seed + 3 + rank, n=B, lo=112, hi=448)
         buf, offsets, hw, strides = synth.pack_crops(images)
         crops_dev = torch.from_numpy(buf).to(dev)
+        log(f"gallery shard: rows [{row_base}, {row_base + rows_local}) x {D}")
         gal = Gallery(ctx, D, rows_local)
         gal.fill_synthetic(seed=args.seed + 1000 * (rank + 1), row0=0, n=rows_local, nkeys=0, dup_every=100)
 
@@ -172,12 +287,14 @@ def main():
             ctx.embed_dev(crops_dev.data_ptr(), offsets, hw, strides, flags, None, q_local.data_ptr(), D)
             last["s"], last["r"] = sharded(q_local)
 
+        log("warmup")
         for _ in range(args.warmup):
             step()
         ctx.timing(True)
         if P > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
+        log("timed region")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -197,32 +314,67 @@ def main():
         res_r = last["r"].cpu().numpy()
         sane = bool((res_r >= 0).all() and (np.diff(res_s, axis=1) <= 0).all() and np.isfinite(res_s).all())
 
-        # Secondary measurement on rank 0: the HBM-bound scan-only shape
-        # (1M x 512 fp16 gallery, 64 queries, top-10), timed with the library's stream events.
-        scan64 = None
+        # Gate of the exchange path, on every rank (also with one): each rank asks for B rows that
+        # are stored in ANOTHER rank's shard (rank r asks for rows of shard r+1), so a correct
+        # answer needs the query gather, that shard's row base and the merge: top-1 must be the
+        # asked global row with score 1 (its planted duplicate second, lower row first).
+        log("exchange gate")
+        pick = (np.arange(B, dtype=np.int64) * 7919 + 13) % max(rows_local, 1)
+        pick[:4] = [98 % rows_local, 99 % rows_local, rows_local - 1, 0]
+        mine16, _ = gal.read(pick)
+        mine = torch.from_numpy(mine16).to(dev)
+        if P > 1 or rehearse:
+            every = torch.empty((P * B, D), dtype=torch.float16, device=dev)
+            dist.all_gather_into_tensor(every, mine)
+        else:
+            every = mine
+        src = (rank + 1) % P
+        gs, gr = sharded(every[src * B:(src + 1) * B].contiguous())
+        torch.cuda.synchronize()
+        gs, gr = gs.cpu().numpy(), gr.cpu().numpy()
+        gate_ok = True
+        for r in range(P):                      # the answer holds every rank's queries: check them all
+            asked_rank = (r + 1) % P
+            base_a, rows_a = shard_rows(args.gallery_rows, P, asked_rank)
+            loc = (np.arange(B, dtype=np.int64) * 7919 + 13) % max(rows_a, 1)
+            loc[:4] = [98 % rows_a, 99 % rows_a, rows_a - 1, 0]
+            first = np.where(loc % 100 == 99, loc - 1, loc) + base_a          # a duplicate pair: lower row first
+            second = np.where(loc % 100 == 98, loc + 1, np.where(loc % 100 == 99, loc, -1))
+            second = np.where((second >= 0) & (second < rows_a), second + base_a, -1)
+            blk_r, blk_s = gr[r * B:(r + 1) * B], gs[r * B:(r + 1) * B]
+            gate_ok &= bool((blk_r[:, 0] == first).all() and (np.abs(blk_s[:, 0] - 1.0) <= 2e-3).all())
+            has2 = second >= 0
+            gate_ok &= bool((blk_r[has2, 1] == second[has2]).all())
+        if P > 1 or rehearse:
+            t = torch.tensor([1 if gate_ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            gate_ok = bool(int(t.item()))
+
+        # PCIe-inclusive leg (one rank): the same crops handed over as pageable host arrays through
+        # frhot_recognise (pack + upload + embed + search + answers back), host wall clock.
+        host_leg = None
+        if P == 1 and not rehearse and not args.no_host_leg:
+            log("host-buffer leg")
+            for _ in range(2):
+                ctx.recognise(gal, images, None, K, gamma=True)
+            n_it = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(n_it):
+                hs, hr, _ = ctx.recognise(gal, images, None, K, gamma=True)
+            dt = time.perf_counter() - t0
+            host_leg = {"value": B * n_it / dt, "unit": "faces/s", "ms_per_batch": dt / n_it * 1e3, "batches": n_it,
+                        "host_bytes_per_batch": int(sum(im.nbytes for im in images)),
+                        "same_answer_as_device_resident": bool(np.array_equal(hr, res_r)),
+                        "what": "frhot_recognise from pageable host crops, answers back on the host"}
+
+        # Secondary measurements on rank 0: scan-only shapes on galleries of their own.
+        scan64 = scan4096 = None
         if rank == 0 and not args.no_scan64:
-            n64, bq64, k64 = 1_000_000, 64, 10
-            gal64 = Gallery(ctx, D, n64)
-            gal64.fill_synthetic(seed=args.seed + 77, row0=0, n=n64, nkeys=0, dup_every=0)
-            q64 = q_local[:bq64].contiguous()
-            s64 = torch.empty((bq64, k64), dtype=torch.float32, device=dev)
-            r64 = torch.empty((bq64, k64), dtype=torch.int64, device=dev)
-            for _ in range(3):
-                gal64.search_dev(q64.data_ptr(), None, bq64, k64, s64.data_ptr(), r64.data_ptr(), 0)
-            ctx.timing(True)
-            for _ in range(20):
-                gal64.search_dev(q64.data_ptr(), None, bq64, k64, s64.data_ptr(), r64.data_ptr(), 0)
-            ms64 = ctx.stage_ms()["scan"]
-            ctx.timing(False)
-            b64 = n64 * D * 2 + bq64 * D * 2
-            tr64, src64 = pmc_traffic(n64, D, bq64, k64)
-            scan64 = {"workload": f"scan only: {n64}x{D} fp16 gallery, {bq64} queries, top-{k64}", "bound": "hbm",
-                      "achieved": b64 / (ms64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": b64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr64,
-                      "traffic_source": src64,
-                      "algorithmic_bytes_per_launch": b64, "ms_per_launch": ms64,
-                      "queries_per_s": bq64 / (ms64 * 1e-3)}
-            gal64.close()
+            log("scan-only shapes")
+            scan64 = scan_only(ctx, Gallery, dev, 1_000_000, 512, 64, 10, args.seed + 77,
+                               "BASELINE config 2 (HBM-bound)", "hbm")
+            scan4096 = scan_only(ctx, Gallery, dev, 1_000_000, 4096, 256, 5, args.seed + 78,
+                                 "BASELINE config 3 at the reference's dimension (ridge)", "hbm", iters=10)
 
         line = None
         if rank == 0:
@@ -256,13 +408,19 @@ def main():
                                  "frac": cnn_tf / MFMA_PEAK_TFLOPS, "gflop_per_face": GFLOP_PER_FACE_CNN,
                                  "ms_per_batch": cnn_ms},
                 "stages_ms": stages, "result_sane": sane,
+                "gates": {"exchange_top1_is_the_asked_row": gate_ok},
             }
+            if host_leg is not None:
+                line["value_pcie_inclusive"] = host_leg["value"]
+                line["pcie_inclusive"] = host_leg
             if scan64 is not None:
                 line["roofline_scan_hbm"] = scan64
-            if P == 1 and not args.no_cpu_baseline:
+                line["roofline_scan_d4096"] = scan4096
+            if P == 1 and not rehearse and not args.no_cpu_baseline:
+                log("cpu baseline")
                 base, gates = cpu_baseline(ctx, gal, images, args, rows_local)
                 line["cpu_baseline"] = base
-                line["gates"] = gates
+                line["gates"].update(gates)
         gal.close()
         ctx.close()
     if world > 1 or rehearse:
@@ -272,6 +430,8 @@ def main():
     if line is not None:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
+    if line is not None and not all(bool(v) for k, v in line["gates"].items() if isinstance(v, bool)):
+        raise SystemExit("bench.py: a correctness gate failed: " + json.dumps(line["gates"]))
 
 
 if __name__ == "__main__":

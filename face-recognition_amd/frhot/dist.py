@@ -6,7 +6,7 @@ embeds its own batch), and the gallery is split by rows (rank r holds global row
 
   1. all-gather the per-rank unit fp16 queries [B, D] -> [P*B, D];
   2. every rank scans ITS shard with all P*B queries -> per-shard top-k with global rows;
-  3. all-gather the per-shard lists [P*B, k] -> [P, P*B, k];
+  3. all-gather the per-shard lists [P*B, k] -> [P, P*B, k] (rows and scores in one buffer);
   4. merge the P lists of every query -> global top-k (same tie rule as one shard:
      descending score, ascending row).
 
@@ -33,9 +33,14 @@ class ShardedSearch:
         self.exchange = world > 1 or always_exchange
         n = world * batch
         self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if self.exchange else None
-        self.s_local = torch.empty((n, k), dtype=torch.float32, device=device)
-        self.r_local = torch.empty((n, k), dtype=torch.int64, device=device)
+        # A shard's answer travels as ONE buffer: its rows (int64) followed by its scores (float32),
+        # so a step makes two collectives (queries out, answers back), both latency-bound.
+        self._nr, self._ns = n * k * 8, n * k * 4
+        self.packed = torch.empty(self._nr + self._ns, dtype=torch.uint8, device=device)
+        self.r_local = self.packed[:self._nr].view(torch.int64).view(n, k)
+        self.s_local = self.packed[self._nr:].view(torch.float32).view(n, k)
         if self.exchange:
+            self.packed_all = torch.empty((world, self._nr + self._ns), dtype=torch.uint8, device=device)
             self.s_all = torch.empty((world, n, k), dtype=torch.float32, device=device)
             self.r_all = torch.empty((world, n, k), dtype=torch.int64, device=device)
             self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
@@ -48,9 +53,11 @@ class ShardedSearch:
             return self.s_local, self.r_local
         dist.all_gather_into_tensor(self.q_all, q_local)
         self.search_local(self.q_all, self.s_local, self.r_local)
-        # the gather output is passed flat ([P*n, k], rank-major): gloo rejects the stacked shape
-        dist.all_gather_into_tensor(self.s_all.view(-1, self.k), self.s_local)
-        dist.all_gather_into_tensor(self.r_all.view(-1, self.k), self.r_local)
+        # the gather output is passed flat (rank-major): gloo rejects the stacked shape
+        dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)
+        # unpack into the two contiguous [P, P*B, k] arrays the merge reads (two small device copies)
+        self.r_all.view(self.P, -1).copy_(self.packed_all[:, :self._nr].view(torch.int64))
+        self.s_all.view(self.P, -1).copy_(self.packed_all[:, self._nr:].view(torch.float32))
         self.merge(self.s_all, self.r_all, self.out_s, self.out_r)
         return self.out_s, self.out_r
 
