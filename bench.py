@@ -355,16 +355,25 @@ def main():
         host_leg = None
         if P == 1 and not rehearse and not args.no_host_leg:
             log("host-buffer leg")
+            from concurrent.futures import ThreadPoolExecutor
             for _ in range(2):
                 ctx.recognise(gal, images, None, K, gamma=True)
-            n_it = max(3, min(args.steps, 10))
-            t0 = time.perf_counter()
-            for _ in range(n_it):
-                hs, hr, _ = ctx.recognise(gal, images, None, K, gamma=True)
-            dt = time.perf_counter() - t0
+            n_it = 2 * max(2, min(args.steps, 10) // 2)
+            # two callers in flight, as the reference's handlers arrive from worker threads
+            # (face_service.py:231-233): while one batch computes, the other's crops are packed and uploaded
+            with ThreadPoolExecutor(max_workers=2) as pool:
+                t0 = time.perf_counter()
+                answers = list(pool.map(lambda _i: ctx.recognise(gal, images, None, K, gamma=True), range(n_it)))
+                dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ctx.recognise(gal, images, None, K, gamma=True)
+            dt_serial = (time.perf_counter() - t1) / 3
+            same = all(np.array_equal(a[1], res_r) for a in answers)
             host_leg = {"value": B * n_it / dt, "unit": "faces/s", "ms_per_batch": dt / n_it * 1e3, "batches": n_it,
+                        "callers_in_flight": 2, "ms_per_batch_one_caller": dt_serial * 1e3,
                         "host_bytes_per_batch": int(sum(im.nbytes for im in images)),
-                        "same_answer_as_device_resident": bool(np.array_equal(hr, res_r)),
+                        "same_answer_as_device_resident": bool(same),
                         "what": "frhot_recognise from pageable host crops, answers back on the host"}
 
         # Secondary measurements on rank 0: scan-only shapes on galleries of their own.

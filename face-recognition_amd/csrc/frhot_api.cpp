@@ -2,6 +2,7 @@
 // pipeline, galleries and search.  Host-side only; kernels live in frhot_kernels.hip.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -116,8 +117,21 @@ struct frhot_ctx {
     void* fc6_out = nullptr;     // fp16 [B,4096]
     float* partial = nullptr;    // split-K partial sums
     // host-call staging
-    uint8_t* crops_dev = nullptr; size_t crops_cap = 0;
-    uint8_t* crops_pin = nullptr; size_t crops_pin_cap = 0;   // page-locked mirror of crops_dev
+    // Host calls (frhot_embed, frhot_recognise) go through one of two staging slots: a page-locked
+    // mirror and a device buffer for the packed crops, a page-locked mirror for the answers, and
+    // two events.  A caller holds its slot for the whole call; packing and the upload (copy
+    // stream) happen before it takes `mu`, so with two callers in flight the crops of batch i+1
+    // are packed and uploaded while batch i computes.
+    struct Slot {
+        std::mutex m;
+        uint8_t* pin = nullptr; size_t pin_cap = 0;
+        uint8_t* dev = nullptr; size_t dev_cap = 0;
+        uint8_t* res_pin = nullptr;                  // [B,16] f32 scores, then [B,16] i64 rows
+        float* emb_pin = nullptr;                    // [B,4096], allocated at the first request for descriptors
+        hipEvent_t uploaded = nullptr, done = nullptr;
+    } slot[2];
+    std::atomic<unsigned> next_slot{0};
+    hipStream_t copy_stream = nullptr;
     float* emb_dev = nullptr;    // [B,4096]
     void* q_dev = nullptr;       // fp16 [B,4096]
     int32_t* qkeys_dev = nullptr;
@@ -236,9 +250,12 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
     return FRHOT_OK;
 }
 
-// Pack host crops tightly into the context's device staging buffer.
-int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, const int32_t* strides, int B,
-                std::vector<int64_t>& offsets, std::vector<int32_t>& packed_strides) {
+// Pack host crops tightly into the slot's page-locked mirror and upload them to the slot's device
+// buffer on the copy stream; `sl.uploaded` is recorded behind the last copy.  The caller holds
+// sl.m, and the slot's previous user has waited for its work before releasing it, so mirror and
+// device buffer are free.  Does not touch the compute stream.
+int stage_crops(frhot_ctx* c, frhot_ctx::Slot& sl, const uint8_t* const* crops, const int32_t* hw,
+                const int32_t* strides, int B, std::vector<int64_t>& offsets, std::vector<int32_t>& packed_strides) {
     if (!crops || !hw || !strides) return fail(FRHOT_EINVAL, "null crop arguments");
     offsets.resize(B); packed_strides.resize(B);
     size_t total = 0;
@@ -250,28 +267,24 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
         packed_strides[i] = 3 * w;
         total += ((size_t)h * 3 * w + 15) & ~(size_t)15;
     }
-    if (total > c->crops_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->crops_cap = 0;
-        HIP_TRY(free_null(c->crops_dev));
+    if (total > sl.dev_cap) {
+        sl.dev_cap = 0;
+        HIP_TRY(free_null(sl.dev));
         const size_t cap = total + total / 4 + 4096;
-        HIP_TRY(hipMalloc((void**)&c->crops_dev, cap));
-        c->crops_cap = cap;
+        HIP_TRY(hipMalloc((void**)&sl.dev, cap));
+        sl.dev_cap = cap;
     }
-    if (total > c->crops_pin_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->crops_pin_cap = 0;
-        if (uint8_t* old = c->crops_pin) { c->crops_pin = nullptr; HIP_TRY(hipHostFree(old)); }
+    if (total > sl.pin_cap) {
+        sl.pin_cap = 0;
+        if (uint8_t* old = sl.pin) { sl.pin = nullptr; HIP_TRY(hipHostFree(old)); }
         const size_t cap = total + total / 4 + 4096;
-        HIP_TRY(hipHostMalloc((void**)&c->crops_pin, cap, hipHostMallocDefault));
-        c->crops_pin_cap = cap;
+        HIP_TRY(hipHostMalloc((void**)&sl.pin, cap, hipHostMallocDefault));
+        sl.pin_cap = cap;
     }
     // The callers' arrays are pageable, and a strided copy out of pageable memory moves row by
     // row.  The crops are packed into the page-locked mirror by a few host threads, each a
     // contiguous run of crops, and every run goes to the device as one asynchronous copy as
-    // soon as its thread is done, while the later runs are still being packed.  The mirror is
-    // reused by every call, so copies that an earlier, failed call left in flight are waited for.
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // soon as its thread is done, while the later runs are still being packed.
     int nthr = (int)(total >> 22);                      // one thread per 4 MiB
     const int hwc = (int)std::thread::hardware_concurrency();
     const int lim = hwc >= 16 ? 8 : (hwc >= 4 ? hwc / 2 : 1);
@@ -284,7 +297,7 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
         while (i < B && (size_t)offsets[i] < total / nthr * t) ++i;
         first[t] = i;
     }
-    uint8_t* const pin = c->crops_pin;
+    uint8_t* const pin = sl.pin;
     auto pack = [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i) {
             const size_t h = (size_t)hw[2 * i], row = (size_t)3 * hw[2 * i + 1];
@@ -315,9 +328,52 @@ int stage_crops(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
         if (err != hipSuccess || first[t] >= first[t + 1]) continue;
         const size_t lo = (size_t)offsets[first[t]];
         const size_t hi = first[t + 1] < B ? (size_t)offsets[first[t + 1]] : total;
-        err = hipMemcpyAsync(c->crops_dev + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, c->stream);
+        err = hipMemcpyAsync(sl.dev + lo, pin + lo, hi - lo, hipMemcpyHostToDevice, c->copy_stream);
     }
-    HIP_TRY(err);
+    if (err == hipSuccess) err = hipEventRecord(sl.uploaded, c->copy_stream);
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(c->copy_stream);      // nothing of this call may still read the mirror
+        HIP_TRY(err);
+    }
+    return FRHOT_OK;
+}
+
+// RAII over one staging slot: the two slots are taken in turn.
+struct SlotLease {
+    frhot_ctx::Slot& sl;
+    explicit SlotLease(frhot_ctx* c) : sl(c->slot[c->next_slot.fetch_add(1) & 1u]) { sl.m.lock(); }
+    ~SlotLease() { sl.m.unlock(); }
+};
+
+// Shared tail of the host calls, entered with the crops staged: under `mu`, make the compute
+// stream wait for the upload, let `enqueue` put the kernels and the copies into the slot's answer
+// mirror on the stream, record `done`; then, without the lock, wait for `done`.  On failure
+// both streams are drained before the slot is released.
+template <class F>
+int run_staged(frhot_ctx* c, frhot_ctx::Slot& sl, F&& enqueue) {
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        hipError_t e = hipStreamWaitEvent(c->stream, sl.uploaded, 0);
+        rc = e == hipSuccess ? enqueue() : fail(FRHOT_EHIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+        if (rc == FRHOT_OK) {
+            e = hipEventRecord(sl.done, c->stream);
+            if (e != hipSuccess) rc = fail(FRHOT_EHIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc != FRHOT_OK) {
+        const std::string keep = g_err;
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        g_err = keep;
+        return rc;
+    }
+    HIP_TRY(hipEventSynchronize(sl.done));
+    return FRHOT_OK;
+}
+
+int slot_emb_mirror(frhot_ctx* c, frhot_ctx::Slot& sl) {
+    if (!sl.emb_pin) HIP_TRY(hipHostMalloc((void**)&sl.emb_pin, (size_t)c->max_batch * kFcN * 4, hipHostMallocDefault));
     return FRHOT_OK;
 }
 
@@ -432,7 +488,13 @@ const char* frhot_version(void) { return "frhot 0.1 gfx950 mfma-f16 igemm/scan";
 
 static int ctx_init(frhot_ctx* c) {
     if (!c->stream) { HIP_TRY(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const int B = c->max_batch;
+    for (auto& sl : c->slot) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&sl.res_pin, (size_t)B * 16 * (4 + 8), hipHostMallocDefault));
+    }
     const size_t x0_bytes = (size_t)B * 226 * 226 * 4 * 2;
     HIP_TRY(hipMalloc(&c->x0, x0_bytes));
     HIP_TRY(hipMemsetAsync(c->x0, 0, x0_bytes, c->stream));
@@ -500,10 +562,19 @@ int frhot_ctx_destroy(frhot_ctx* c) {
     if (!c) return FRHOT_OK;
     DeviceGuard dg(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial, c->crops_dev,
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& sl : c->slot) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.res_pin) (void)hipHostFree(sl.res_pin);
+        if (sl.emb_pin) (void)hipHostFree(sl.emb_pin);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial,
                     c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->w6, c->w7, c->b6, c->b7};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (c->crops_pin) (void)hipHostFree(c->crops_pin);
     for (int l = 0; l < kNumConv; ++l) {
         if (c->act[l]) (void)hipFree(c->act[l]);
         if (c->w[l]) (void)hipFree(c->w[l]);
@@ -608,15 +679,21 @@ int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     return guarded([&]() -> int {
     if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
     if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
-    std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
+    SlotLease lease(c);
     std::vector<int64_t> offsets; std::vector<int32_t> ps;
-    int rc = stage_crops(c, crops, hw, strides, B, offsets, ps);
+    int rc = slot_emb_mirror(c, lease.sl);
     if (rc) return rc;
-    rc = embed_enqueue(c, c->crops_dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, nullptr, kFcN);
+    rc = stage_crops(c, lease.sl, crops, hw, strides, B, offsets, ps);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = run_staged(c, lease.sl, [&]() -> int {
+        int r = embed_enqueue(c, lease.sl.dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, nullptr, kFcN);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(lease.sl.emb_pin, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, c->stream));
+        return FRHOT_OK;
+    });
+    if (rc) return rc;
+    memcpy(out, lease.sl.emb_pin, (size_t)B * kFcN * 4);
     return FRHOT_OK;
     });
 }
@@ -903,21 +980,32 @@ int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops,
         for (int i = 0; i < B; ++i)
             if (qkeys[i] < 0 && qkeys[i] != FRHOT_KEY_ANY)
                 return fail(FRHOT_EINVAL, "query key %d of crop %d is neither a row key nor FRHOT_KEY_ANY", qkeys[i], i);
-    std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
+    SlotLease lease(c);
+    frhot_ctx::Slot& sl = lease.sl;
     std::vector<int64_t> offsets; std::vector<int32_t> ps;
-    int rc = stage_crops(c, crops, hw, strides, B, offsets, ps);
+    int rc = emb_out ? slot_emb_mirror(c, sl) : FRHOT_OK;
     if (rc) return rc;
-    hipStream_t s = c->stream;
-    if (qkeys) HIP_TRY(hipMemcpyAsync(c->qkeys_dev, qkeys, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    rc = embed_enqueue(c, c->crops_dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D);
+    rc = stage_crops(c, sl, crops, hw, strides, B, offsets, ps);
     if (rc) return rc;
-    rc = search_enqueue(g, c->q_dev, qkeys ? c->qkeys_dev : nullptr, B, k, c->res_s, c->res_r, 0);
+    float* const pin_s = (float*)sl.res_pin;
+    int64_t* const pin_r = (int64_t*)(sl.res_pin + (size_t)c->max_batch * 16 * 4);
+    rc = run_staged(c, sl, [&]() -> int {
+        hipStream_t s = c->stream;
+        if (qkeys) HIP_TRY(hipMemcpyAsync(c->qkeys_dev, qkeys, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        int r = embed_enqueue(c, sl.dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D);
+        if (r) return r;
+        r = search_enqueue(g, c->q_dev, qkeys ? c->qkeys_dev : nullptr, B, k, c->res_s, c->res_r, 0);
+        if (r) return r;
+        if (emb_out) HIP_TRY(hipMemcpyAsync(sl.emb_pin, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(pin_s, c->res_s, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(pin_r, c->res_r, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+        return FRHOT_OK;
+    });
     if (rc) return rc;
-    if (emb_out) HIP_TRY(hipMemcpyAsync(emb_out, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(scores, c->res_s, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(rows, c->res_r, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (emb_out) memcpy(emb_out, sl.emb_pin, (size_t)B * kFcN * 4);
+    memcpy(scores, pin_s, (size_t)B * k * 4);
+    memcpy(rows, pin_r, (size_t)B * k * 8);
     return FRHOT_OK;
     });
 }

@@ -340,7 +340,7 @@ def test_dead_key_as_query_key_matches_nothing(gpu_ctx):
     with pytest.raises(FrhotError):
         gal.search(g[:4], np.array([0, 1, -7, 2], np.int32), 5)
     dev = torch.device("cuda", 0)
-    q16 = torch.from_numpy(g[:6].astype(np.float16)).to(dev)
+    q16 = torch.from_numpy(g[[0, 1, 1, 3, 4, 0]].astype(np.float16)).to(dev)
     qk = torch.tensor([-1, -2, 1, -5, -2147483648, 0], dtype=torch.int32, device=dev)
     s = torch.empty((6, 5), dtype=torch.float32, device=dev)
     r = torch.empty((6, 5), dtype=torch.int64, device=dev)
@@ -387,6 +387,43 @@ def test_recognise_fused_equals_two_calls(gpu_ctx):
     assert np.array_equal(r1, r2)
     assert np.abs(s1 - s2).max() <= 2e-3      # fp16 query rounding differs (f32->unit->f16 vs fused)
     assert r2[1, 0] == 17 and r2[3, 0] == 333 and s2[1, 0] > 0.999
+    gal.close()
+
+
+def test_concurrent_host_calls_overlap_safely(gpu_ctx):
+    """Host calls from several threads at once (the reference embeds from up to 10 worker threads,
+    face_service.py:43,231-233): each goes through one of two staging slots, packing and upload
+    of one call overlapping the compute of another.  Every caller gets exactly the answer it gets
+    alone, for crops of very different sizes (the slots' buffers grow) and for both entry points."""
+    from concurrent.futures import ThreadPoolExecutor
+    from frhot import synth
+    from frhot.engine import Gallery
+    rng = np.random.default_rng(90)
+    batches = []
+    for i in range(6):
+        n = int(rng.integers(1, 17))
+        lo, hi = ((40, 90), (300, 700), (100, 200))[i % 3]
+        batches.append(synth.crops(seed=900 + i, n=n, lo=lo, hi=hi))
+    g = synth.unit_gallery(seed=91, n=2000, d=4096, sparse=True)
+    gal = Gallery(gpu_ctx, 4096, 2000)
+    gal.upsert(g, 0, np.arange(2000))
+    alone_e = [gpu_ctx.embed(b, gamma=True) for b in batches]
+    alone_r = [gpu_ctx.recognise(gal, b, None, 5, gamma=True, want_embeddings=True) for b in batches]
+
+    def work(j):
+        i = j % len(batches)
+        if j % 2:
+            return ("e", i, gpu_ctx.embed(batches[i], gamma=True))
+        return ("r", i, gpu_ctx.recognise(gal, batches[i], None, 5, gamma=True, want_embeddings=True))
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(work, range(48)))
+    for kind, i, out in results:
+        if kind == "e":
+            assert np.array_equal(out, alone_e[i])
+        else:
+            assert np.array_equal(out[0], alone_r[i][0]) and np.array_equal(out[1], alone_r[i][1])
+            assert np.array_equal(out[2], alone_r[i][2]) and np.array_equal(out[2], alone_e[i])
     gal.close()
 
 
