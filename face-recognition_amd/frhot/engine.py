@@ -111,6 +111,21 @@ class Context:
         check(self._lib.frhot_debug_read(self._h, stage, n, C.c_void_p(out.ctypes.data), out.nbytes))
         return out
 
+    def activation_peaks(self, n: int):
+        """Range check after an embed of n crops: (largest stored magnitude per stage, all finite?)
+        for conv1_1 .. conv5_3 and fc6, in the fp16 units the library computes in (input_scale x
+        the network's activations).  A stage that overflowed fp16 holds inf; later layers can turn
+        it into NaN and ReLU turns NaN into 0, so an out-of-range model does NOT always show in
+        its descriptors: run this on representative crops after loading new weights and lower
+        input_scale until every peak stays well below 65504."""
+        peaks, finite = [], True
+        for stage in list(range(10, 23)) + [30]:
+            a = self.debug_read(stage, n).astype(np.float32)
+            ok = np.isfinite(a)
+            finite = finite and bool(ok.all())
+            peaks.append(float(np.abs(a[ok]).max()) if ok.any() else float("inf"))
+        return peaks, finite
+
     def timing(self, enable: bool = True):
         check(self._lib.frhot_ctx_timing(self._h, 1 if enable else 0))
 

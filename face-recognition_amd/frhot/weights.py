@@ -52,6 +52,65 @@ def synthetic_weights(seed: int = 0xFACE, bias_scale: float = 0.5) -> dict:
     return out
 
 
+def scaled_weights(weights: dict, alpha: float) -> dict:
+    """The same network with every activation multiplied by `alpha` (> 0): conv1_1's kernel and
+    every bias are scaled, which by the positive homogeneity of ReLU(Wx + b) scales every layer's
+    output and leaves the unit descriptor unchanged.  Drives the activation range of a test."""
+    a = np.float32(alpha)
+    out = {k: v.copy() for k, v in weights.items()}
+    out["conv1_1.w"] = out["conv1_1.w"] * a
+    for name, *_ in LAYERS:
+        out[name + ".b"] = out[name + ".b"] * a
+    return out
+
+
+def growing_weights(seed: int = 0xFACE, gain: float = 1.25, bias_scale: float = 0.5) -> dict:
+    """He-normal kernels whose standard deviation grows by `gain` per convolution layer, so that
+    activations rise through the stack and peak in conv5_x / fc6 instead of staying level."""
+    out = synthetic_weights(seed, bias_scale)
+    g = np.float32(1.0)
+    for name, *_ in LAYERS[:13]:
+        g = g * np.float32(gain)
+        out[name + ".w"] = out[name + ".w"] * np.float32(gain)
+        out[name + ".b"] = out[name + ".b"] * g
+    for name in ("fc6", "fc7"):
+        out[name + ".b"] = out[name + ".b"] * g
+    return out
+
+
+def heavy_tailed_weights(seed: int = 0xFACE, df: float = 3.0, bias_scale: float = 0.5) -> dict:
+    """Kernels drawn from Student's t (df degrees of freedom) scaled to the He variance: a few
+    taps per filter are many standard deviations large, as trained filters' are."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, kh, kw, cin, cout in LAYERS:
+        fan_in = kh * kw * cin
+        std = np.sqrt(2.0 / fan_in) / np.sqrt(df / (df - 2.0))
+        w = rng.standard_t(df, size=weight_shape(name, kh, kw, cin, cout)).astype(np.float32) * np.float32(std)
+        out[name + ".w"] = w
+        out[name + ".b"] = rng.standard_normal(size=(cout,), dtype=np.float32) * np.float32(bias_scale)
+    return out
+
+
+def discriminative_weights(weights: dict, fc6_sample: np.ndarray, thr_mult: float = 1.6) -> dict:
+    """The same stack with an fc7 that tells inputs apart.  Descriptors of a randomly initialised
+    ReLU network all point the same way (pairwise cosine 0.94-0.98): every search hit passes the
+    0.54 threshold.  Here fc7 ignores the direction the fc6 outputs share (the mean of
+    `fc6_sample`, [n, 4096] fc6 activations of a few inputs, is projected out of its kernel) and
+    its bias is -thr_mult standard deviations of the remaining response, so that a few percent
+    of the units fire and which ones depends on the input: different inputs score well below
+    0.54, an input scores 1 against itself."""
+    h = np.asarray(fc6_sample, dtype=np.float64)
+    m = h.mean(axis=0)
+    w7 = np.asarray(weights["fc7.w"], dtype=np.float64)
+    w7p = w7 - np.outer(w7 @ m, m) / float(m @ m)
+    z = h @ w7p.T
+    out = {k: v.copy() for k, v in weights.items()}
+    out["fc7.w"] = w7p.astype(np.float32)
+    out["fc7.b"] = np.full(w7.shape[0], -thr_mult * z.std(), dtype=np.float32)
+    return out
+
+
 def quantize_fp16(weights: dict) -> dict:
     """Weights as the library stores them: fp16-rounded matrices, fp32 biases (returned as float32)."""
     return {k: (v.astype(np.float16).astype(np.float32) if k.endswith(".w") else v.astype(np.float32))

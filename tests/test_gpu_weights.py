@@ -1,0 +1,185 @@
+"""The network under weight sets that stress what the He-normal default does not: activation
+ranges from 1e3 to the edge of fp16 (the library computes on input_scale x the activations),
+activations that grow with depth, heavy-tailed kernels, and an fc7 that makes descriptors
+discriminative, so that the 0.54 threshold and the id vote decide something on the GPU.
+Tolerance everywhere: cosine >= 0.9999 against the float32 oracle (the north star's)."""
+import numpy as np
+import pytest
+
+from conftest import cosine_rows
+
+pytestmark = pytest.mark.gpu
+
+SCALE = 1.0 / 16.0
+
+
+def _ctx(weights, input_scale=SCALE, max_batch=16):
+    from frhot.engine import Context
+    from frhot.weights import pack_blob
+    ctx = Context(device=0, max_batch=max_batch)
+    ctx.load_model(pack_blob(weights), input_scale=input_scale)
+    return ctx
+
+
+def _stage_peaks(ctx, n, input_scale):
+    """Largest activation per stage in the network's own units, and whether all are finite."""
+    peaks, finite = ctx.activation_peaks(n)
+    return [p / input_scale for p in peaks], finite
+
+
+@pytest.fixture(scope="module")
+def crops_and_inputs():
+    from frhot import synth
+    from oracle import preprocess as op
+    imgs = synth.crops(seed=71, n=3, lo=120, hi=320)
+    x = np.stack([op.preprocess(im, apply_gamma=True) for im in imgs])
+    return imgs, x
+
+
+def test_activation_range_up_to_the_fp16_edge(weights_f32, crops_and_inputs):
+    """The same descriptor whatever the activation scale, as long as input_scale x peak stays
+    below 65504: peaks of about 1e3, 1e4, 6e4 and 9e5 (56,000 in the library's fp16) all meet the
+    tolerance with no inf/NaN at any stage; beyond the edge the range check (activation_peaks)
+    reports non-finite stages (the descriptors themselves may look plausible: ReLU turns NaN into
+    0), and a smaller input_scale brings the same weights back inside the tolerance."""
+    from frhot.weights import scaled_weights
+    from oracle import vggface
+    imgs, x = crops_and_inputs
+    ref = vggface.embed(x, weights_f32)
+    base = _ctx(weights_f32)
+    base.embed(imgs, gamma=True)
+    peaks, ok = _stage_peaks(base, len(imgs), SCALE)
+    base.close()
+    assert ok
+    peak = max(peaks)
+    assert 2e2 < peak < 2e4
+    for target in (1e3, 1e4, 6e4, 9e5):
+        w = scaled_weights(weights_f32, target / peak)
+        ctx = _ctx(w)
+        got = ctx.embed(imgs, gamma=True)
+        pk, finite = _stage_peaks(ctx, len(imgs), SCALE)
+        ctx.close()
+        assert finite and np.isfinite(got).all(), f"peak {target:g}: non-finite values"
+        assert 0.9 * target <= max(pk) <= 1.1 * target
+        assert cosine_rows(got, ref).min() >= 0.9999, f"peak {target:g}"
+        if target == 1e4:
+            assert cosine_rows(got, vggface.embed(x, w)).min() >= 0.9999      # the scaled network itself
+    w = scaled_weights(weights_f32, 4e6 / peak)
+    ctx = _ctx(w)
+    got = ctx.embed(imgs, gamma=True)
+    _pk, finite = ctx.activation_peaks(len(imgs))
+    ctx.close()
+    assert not finite and (not np.isfinite(got).all() or cosine_rows(got, ref).min() < 0.9999)
+    ctx = _ctx(w, input_scale=1.0 / 1024.0)
+    got = ctx.embed(imgs, gamma=True)
+    ctx.close()
+    assert np.isfinite(got).all() and cosine_rows(got, ref).min() >= 0.9999
+
+
+@pytest.mark.parametrize("kind", ["growing", "heavy_tailed"])
+def test_other_weight_statistics(kind, crops_and_inputs):
+    from frhot.weights import growing_weights, heavy_tailed_weights, quantize_fp16
+    from oracle import vggface
+    imgs, x = crops_and_inputs
+    w = growing_weights(seed=0xBEEF, gain=1.25) if kind == "growing" else heavy_tailed_weights(seed=0xBEEF, df=3.0)
+    ctx = _ctx(w)
+    got = ctx.embed(imgs, gamma=True)
+    peaks, finite = _stage_peaks(ctx, len(imgs), SCALE)
+    ctx.close()
+    assert finite and np.isfinite(got).all()
+    if kind == "growing":
+        assert peaks[12] > 4 * peaks[1]                   # conv5_3 far above conv1_2
+    assert (got >= 0).all() and np.allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=1e-5)
+    assert cosine_rows(got, vggface.embed(x, quantize_fp16(w))).min() >= 0.9999
+    assert cosine_rows(got, vggface.embed(x, w)).min() >= 0.9999
+
+
+@pytest.fixture(scope="module")
+def disc_ctx(weights_f32):
+    """A context whose fc7 is discriminative (fc6 statistics taken from 8 crops on the GPU)."""
+    from frhot import synth
+    from frhot.weights import discriminative_weights
+    sample = synth.crops(seed=500, n=8, lo=112, hi=300)
+    base = _ctx(weights_f32)
+    base.embed(sample, gamma=True)
+    h = base.debug_read(30, len(sample)).astype(np.float32) / SCALE
+    base.close()
+    w = discriminative_weights(weights_f32, h)
+    ctx = _ctx(w)
+    yield ctx, w
+    ctx.close()
+
+
+def test_discriminative_descriptors_and_channel_flip_both_ways(disc_ctx):
+    """Different crops score below the 0.54 threshold, a crop scores 1 against itself, the sparse
+    fc7 meets the tolerance against the oracle; and the channel reverse that DeepFace.represent
+    performs is pinned both ways: with it (default) and without it (FRHOT_FLAG_NOFLIP) the library
+    follows the oracle's flip=True / flip=False, and the two differ from each other."""
+    from frhot import synth
+    from oracle import preprocess as op, vggface
+    ctx, w = disc_ctx
+    imgs = synth.crops(seed=600, n=12, lo=112, hi=300)
+    got = ctx.embed(imgs, gamma=True)
+    c = got.astype(np.float64) @ got.astype(np.float64).T
+    off = c[~np.eye(len(imgs), dtype=bool)]
+    assert off.max() < 0.54 and np.allclose(np.diag(c), 1.0, atol=1e-5), f"max off-diagonal cosine {off.max()}"
+    assert 0.01 < (got > 0).mean() < 0.25
+    x = np.stack([op.preprocess(im, apply_gamma=True) for im in imgs[:4]])
+    assert cosine_rows(got[:4], vggface.embed(x, w)).min() >= 0.9999
+    noflip = ctx.embed(imgs[:4], gamma=True, flip=False)
+    x_nf = np.stack([op.preprocess(im, apply_gamma=True, flip=False) for im in imgs[:4]])
+    assert cosine_rows(noflip, vggface.embed(x_nf, w)).min() >= 0.9999
+    assert cosine_rows(noflip, got[:4]).max() < 0.999
+
+
+def test_threshold_and_vote_decide_on_the_gpu(disc_ctx):
+    """The two routes on discriminative descriptors: enrolling a second, different person WITHOUT
+    is_update answers 201 (the pre-search finds nobody above 0.54, face_service.py:566-579), the
+    same person again 409, everyone is recognised as themselves (threshold and vote of
+    qdrant_database_FE/app.py:340-384 on real scores), a stranger and another store get 404."""
+    import asyncio
+    import base64
+    import io
+
+    import httpx
+    from PIL import Image
+
+    from frhot import legacy, synth
+    from frhot.api import create_app
+    ctx, _w = disc_ctx
+
+    def b64(img):
+        buf = io.BytesIO()
+        Image.fromarray(img[:, :, ::-1]).save(buf, format="PNG")
+        return base64.b64encode(buf.getvalue()).decode()
+
+    rng = np.random.default_rng(77)
+    people = [b64(synth.crop(rng, int(rng.integers(120, 300)), int(rng.integers(120, 300)))) for _ in range(6)]
+    stranger = b64(synth.crop(rng, 200, 180))
+    app = create_app(ctx, capacity=256, api_key="k", max_delay_s=0.02)
+    H = {"X-API-Key": "k"}
+
+    async def run():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot") as c:
+            for i, img in enumerate(people):
+                r = await c.post("/create_face_img_base64", headers=H, json={
+                    "img_base64": img, "id": str(100 + i), "name": f"P{i}", "role": "1", "store_id": "S"})
+                assert r.status_code == 201, (i, r.text)            # nobody enrolled so far resembles this face
+            r = await c.post("/create_face_img_base64", headers=H, json={
+                "img_base64": people[2], "id": "999", "name": "Dup", "role": "1", "store_id": "S"})
+            assert r.status_code == 409 and r.json() == {"status": 0, "message": "Face is existed! Please use another face"}
+            rs = await asyncio.gather(*[c.post("/face_recog_img_base64", headers=H, json={
+                "img_base64": img, "role": "1", "store_id": "S"}) for img in people])
+            for i, r in enumerate(rs):
+                assert r.status_code == 200 and r.json() == {"status": 1, "id": str(100 + i), "name": f"P{i}"}, r.text
+            r = await c.post("/face_recog_img_base64", headers=H, json={"img_base64": stranger, "role": "1", "store_id": "S"})
+            assert r.status_code == 404 and r.json()["status"] == 0
+            r = await c.post("/face_recog_img_base64", headers=H, json={"img_base64": people[0], "role": "1", "store_id": "T"})
+            assert r.status_code == 404                                 # another store's collection
+    try:
+        asyncio.run(run())
+    finally:
+        app.state.batcher.close()
+        app.state.search_batcher.close()
+        app.state.gallery_service.close()
+        legacy.install_engine(None)
