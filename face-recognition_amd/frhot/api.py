@@ -64,10 +64,14 @@ def build_router(face_service, api_key: str = DEFAULT_API_KEY) -> APIRouter:
     return router
 
 
-def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002) -> FastAPI:
-    """A FastAPI app serving the two routes from one GPU context with a loaded model."""
+def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002,
+               fused: bool = True) -> FastAPI:
+    """A FastAPI app serving the two routes from one GPU context with a loaded model.
+    `fused`: requests in flight together share ONE frhot_recognise call each round (crops in,
+    voted answers out); False serves through the two seams get_embedding / search_point with one
+    micro-batcher each, as a maintainer who patches only those seams would run it."""
     from . import legacy
-    from .batcher import EmbedBatcher, SearchBatcher
+    from .batcher import EmbedBatcher, RecogniseBatcher, SearchBatcher
     from .database_client import DatabaseClient
     from .face_service import FaceService
     from .gallery_service import GalleryService
@@ -76,18 +80,26 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
     legacy.install_engine(batcher)
     service = GalleryService(ctx, capacity=capacity)
     search_batcher = SearchBatcher(service, max_delay_s=max_delay_s)
-    face_service = FaceService(DatabaseClient(service, search_batcher))
+    recogniser = RecogniseBatcher(service, ctx.max_batch, max_delay_s=max_delay_s) if fused else None
+    face_service = FaceService(DatabaseClient(service, search_batcher), recogniser=recogniser,
+                               max_in_flight=ctx.max_batch)
     app = FastAPI(title="frhot recognition path")
     app.include_router(build_router(face_service, api_key))
     app.state.batcher = batcher
     app.state.search_batcher = search_batcher
     app.state.gallery_service = service
     app.state.face_service = face_service
+    app.state.recogniser = recogniser
 
-    @app.on_event("shutdown")
-    def _shutdown():
+    def close():
         batcher.close()
         search_batcher.close()
+        if recogniser is not None:
+            recogniser.close()
         service.close()
+        legacy.install_engine(None)
+
+    app.state.close = close
+    app.router.on_shutdown.append(close)
 
     return app

@@ -161,3 +161,48 @@ class SearchBatcher(_MicroBatcher):
             b[1].set_result(ans)
         self.batches += 1
         self.items += len(batch)
+
+
+class RecogniseBatcher(_MicroBatcher):
+    """Groups concurrent recognise / enrol requests into one GalleryService.recognise_points call
+    (one frhot_recognise: crops in, voted answers out, descriptors stay in HBM)."""
+
+    def __init__(self, service, max_batch: int, max_delay_s: float = 0.002):
+        self.service = service
+        super().__init__(max_batch, max_delay_s, "frhot-recognise-batcher")
+
+    def submit(self, collection_name, crop: np.ndarray, store_id, want_embedding: bool = False) -> Future:
+        """Queue one crop (uint8 BGR, not gamma-adjusted: the device applies the LUT); the future
+        resolves to (status_code, content, descriptor or None)."""
+        bad = crop_problem(crop)
+        if bad is not None:
+            fut: Future = Future()
+            fut.set_exception(ValueError(bad))
+            return fut
+        return self._put((collection_name, crop, store_id, bool(want_embedding)))
+
+    def _dispatch(self, batch):
+        reqs = [b[0][:3] for b in batch]
+        want = any(b[0][3] for b in batch)
+        try:
+            answers = self.service.recognise_points(reqs, want_embeddings=want)
+            self.batches += 1
+        except Exception as e:
+            if len(batch) == 1:
+                batch[0][1].set_exception(e)
+                self.batches += 1
+                self.items += 1
+                return
+            answers = []
+            for b in batch:         # one at a time: only the request the library refuses fails
+                try:
+                    answers.append(self.service.recognise_points([b[0][:3]], want_embeddings=b[0][3])[0])
+                except Exception as e1:
+                    answers.append(e1)
+                self.batches += 1
+        for b, ans in zip(batch, answers):
+            if isinstance(ans, Exception):
+                b[1].set_exception(ans)
+            else:
+                b[1].set_result(ans if b[0][3] else ans[:2] + (None,))
+        self.items += len(batch)

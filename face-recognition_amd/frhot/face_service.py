@@ -56,13 +56,22 @@ def decode_image(img_base64: str) -> np.ndarray:
 
 
 class FaceService:
-    def __init__(self, database_client, image_sink=None, decoder=None):
+    def __init__(self, database_client, image_sink=None, decoder=None, recogniser=None, max_in_flight=None):
         """`decoder`: base64 string -> pixel array; default decode_image (PIL).  A host with OpenCV
         passes `lambda b: cv2.imdecode(np.frombuffer(base64.b64decode(b), np.uint8), -1)` to decode
         exactly as the reference does."""
         self.database_client = database_client
         self.image_sink = image_sink
         self.decoder = decoder or decode_image
+        # `recogniser`: a frhot.batcher.RecogniseBatcher.  With it, embedding and search of a request
+        # are one fused device call shared with the requests in flight beside it (the descriptor
+        # never becomes a Python list); without it the two seams get_embedding / search_point are
+        # used as in the reference.  `max_in_flight` bounds the requests inside the fused step
+        # (the reference's limit of 10 bounds CPU threads, face_service.py:43; here it bounds the
+        # device batch).
+        self.recogniser = recogniser
+        self._fused_limit = max_in_flight or PROCESSING_SEMAPHORE_LIMIT
+        self._fused_sem = None
         self._http_sem = None
         self._proc_sem = None
         self._pool = ThreadPoolExecutor(max_workers=PROCESSING_SEMAPHORE_LIMIT, thread_name_prefix="frhot-embed")
@@ -113,6 +122,40 @@ class FaceService:
                 return False, JSONResponse(status_code=500, content={
                     'status': 2, 'message': "Error when processing face! Please try again"})
 
+    def _decode_and_crop(self, data):
+        """face_service.py:65-66,127-131,145-150,180-181 without the gamma LUT (the device applies it)."""
+        img_decode = self.decoder(data.img_base64)
+        img_size = img_decode.shape
+        x, y, w, h = 0, 0, img_size[1], img_size[0]
+        return img_decode, img_decode[int(y):int(y + h), int(x):int(x + w)].astype('uint8')
+
+    async def _fused(self, data, collection_name: str, want_embedding: bool):
+        """decode -> crop -> ONE device call (gamma LUT + descriptor + search + vote input).
+        Returns (False, JSONResponse) with the reference's failure bodies, or
+        (True, (embedding or None, img_decode, search_result))."""
+        if self._fused_sem is None:
+            self._fused_sem = asyncio.Semaphore(self._fused_limit)
+        loop = asyncio.get_running_loop()
+        async with self._fused_sem:
+            try:
+                img_decode, face = await loop.run_in_executor(self._pool, self._decode_and_crop, data)
+            except Exception as e:
+                logger.warning(f"{data.store_id} - Error when decoding image: {e}")
+                return False, JSONResponse(status_code=500, content={
+                    'status': 2, 'message': "Error when detecting face! Please try again"})
+            try:
+                fut = self.recogniser.submit(collection_name, face, data.store_id, want_embedding)
+                status, content, emb = await asyncio.wrap_future(fut)
+            except Exception as e:
+                logger.warning(f"{data.store_id} - Error when encoding face: {e}")
+                return False, JSONResponse(status_code=500, content={
+                    'status': 2, 'message': "Error! Please try again"})
+        if status == 200 and content.get("message") == "Point found":
+            result = {"message": "Point found", "data": [[s, p] for s, p in content.get("data", [])]}
+        else:
+            result = {"message": "Point not found", "data": []}
+        return True, (emb, img_decode, result)
+
     async def search_face(self, collection_name: str, embedding: List[float], store_id: str) -> Dict[str, Any]:
         """face_service.py:275-308."""
         http, _ = self._sems()
@@ -155,18 +198,26 @@ class FaceService:
                 collection_name, is_checkin = f'{data.store_id}_Customers', False
             else:
                 return JSONResponse(status_code=400, content={'status': 2, 'message': "Invalid role"})
-            collection_exists, (check_emb, message) = await asyncio.gather(
-                self.database_client.ensure_collections_exist(data.store_id),
-                self.detect_and_embed_face(data, is_checkin=is_checkin))
-            if not collection_exists:
-                return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when create collection"})
-            if not check_emb:
-                return message
-            emb, img_decode = message
-            if emb is None:
-                await self._save(data, img_decode, "Unknown", "Unknown")
-                return JSONResponse(status_code=200, content={'status': 1, 'id': "Unknown", 'name': "Unknown"})
-            search_result = await self.search_face(collection_name, emb, data.store_id)
+            if self.recogniser is not None:
+                if not await self.database_client.ensure_collections_exist(data.store_id):
+                    return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when create collection"})
+                ok, message = await self._fused(data, collection_name, want_embedding=False)
+                if not ok:
+                    return message
+                _emb, img_decode, search_result = message
+            else:
+                collection_exists, (check_emb, message) = await asyncio.gather(
+                    self.database_client.ensure_collections_exist(data.store_id),
+                    self.detect_and_embed_face(data, is_checkin=is_checkin))
+                if not collection_exists:
+                    return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when create collection"})
+                if not check_emb:
+                    return message
+                emb, img_decode = message
+                if emb is None:
+                    await self._save(data, img_decode, "Unknown", "Unknown")
+                    return JSONResponse(status_code=200, content={'status': 1, 'id': "Unknown", 'name': "Unknown"})
+                search_result = await self.search_face(collection_name, emb, data.store_id)
             face_id, name, _time_created = self.extract_face_info(search_result)
             if face_id == "Unknown" and name == "Unknown":
                 return JSONResponse(status_code=404, content={
@@ -200,23 +251,34 @@ class FaceService:
             collection_name = f'{store_id}_Customers'
         else:
             return JSONResponse(status_code=400, content={'status': 2, 'message': "Invalid role"})
-        collection_exists, (check_emb, message) = await asyncio.gather(
-            self.database_client.ensure_collections_exist(store_id),
-            self.detect_and_embed_face(data, is_checkin=False))
-        if not collection_exists:
-            return JSONResponse(status_code=500, content={'status': 2, 'message': "Error! Please try again"})
-        if not check_emb:
-            return message
-        emb, img_decode = message
-        if emb is None:
-            await self._save(data, img_decode, id_value, name_value, is_checkin=False)
-            return JSONResponse(status_code=200, content={
-                'status': 1, 'message': f'{verb} face {name_value} with id {id_value} successfully'})
-        if not data.is_update:
-            search_result = await self.search_face(collection_name, emb, store_id)
-            if search_result.get('data') and len(search_result['data']) > 0:
+        if self.recogniser is not None:
+            if not await self.database_client.ensure_collections_exist(store_id):
+                return JSONResponse(status_code=500, content={'status': 2, 'message': "Error! Please try again"})
+            ok, message = await self._fused(data, collection_name, want_embedding=True)
+            if not ok:
+                return message
+            emb, img_decode, search_result = message
+            if not data.is_update and search_result.get('data'):
                 return JSONResponse(status_code=409, content={
                     'status': 0, 'message': "Face is existed! Please use another face"})
+        else:
+            collection_exists, (check_emb, message) = await asyncio.gather(
+                self.database_client.ensure_collections_exist(store_id),
+                self.detect_and_embed_face(data, is_checkin=False))
+            if not collection_exists:
+                return JSONResponse(status_code=500, content={'status': 2, 'message': "Error! Please try again"})
+            if not check_emb:
+                return message
+            emb, img_decode = message
+            if emb is None:
+                await self._save(data, img_decode, id_value, name_value, is_checkin=False)
+                return JSONResponse(status_code=200, content={
+                    'status': 1, 'message': f'{verb} face {name_value} with id {id_value} successfully'})
+            if not data.is_update:
+                search_result = await self.search_face(collection_name, emb, store_id)
+                if search_result.get('data') and len(search_result['data']) > 0:
+                    return JSONResponse(status_code=409, content={
+                        'status': 0, 'message': "Face is existed! Please use another face"})
         success = await self.database_client.insert_point(
             collection_name=collection_name, vector_embedding=emb, id=id_value, name=name_value,
             store_id=store_id, is_update_id=False)

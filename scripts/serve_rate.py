@@ -33,16 +33,11 @@ def b64_jpeg(img):
     return base64.b64encode(buf.getvalue()).decode()
 
 
-async def main():
-    conc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    total = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    enrolled = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    ctx = Context(device=0, max_batch=256)
-    ctx.load_model(pack_blob(synthetic_weights(seed=0xFACE)), input_scale=1.0 / 16.0)
-    app = create_app(ctx, capacity=1 << 16, api_key="k", max_delay_s=0.004)
-    rng = np.random.default_rng(5)
-    faces = [b64_jpeg(synth.crop(rng, int(rng.integers(160, 400)), int(rng.integers(160, 400)))) for _ in range(enrolled)]
+async def run(ctx, fused, conc, total, faces):
+    app = create_app(ctx, capacity=1 << 16, api_key="k", max_delay_s=0.004, fused=fused)
+    enrolled = len(faces)
     H = {"X-API-Key": "k"}
+    answers = {}
     async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot", timeout=120) as c:
         for i, img in enumerate(faces):
             r = await c.post("/create_face_img_base64", headers=H, json={
@@ -56,20 +51,36 @@ async def main():
             async with sem:
                 r = await c.post("/face_recog_img_base64", headers=H, json={
                     "img_base64": faces[i % enrolled], "role": "1", "store_id": "S"})
+                answers[i] = (r.status_code, r.json())
                 ok += r.status_code == 200 and r.json().get("id") == str(i % enrolled)
         await asyncio.gather(*[one(i) for i in range(min(total, 2 * conc))])      # warm-up
         ok = 0
-        b0, s0 = app.state.batcher.batches, app.state.search_batcher.batches
+        st = app.state
+        c0 = (st.batcher.batches, st.search_batcher.batches, st.recogniser.batches if fused else 0)
         t0 = time.perf_counter()
         await asyncio.gather(*[one(i) for i in range(total)])
         dt = time.perf_counter() - t0
-        nb, ns = app.state.batcher.batches - b0, app.state.search_batcher.batches - s0
-    print(f"serve: {total} recognise requests, {conc} in flight: {total / dt:.0f} requests/s, {dt / total * 1e3:.2f} ms each; "
-          f"{ok} answered with the enrolled id; {nb} embed calls ({total / max(nb, 1):.1f} crops each), "
-          f"{ns} scans ({total / max(ns, 1):.1f} queries each)")
-    app.state.batcher.close()
-    app.state.search_batcher.close()
-    app.state.gallery_service.close()
+        c1 = (st.batcher.batches, st.search_batcher.batches, st.recogniser.batches if fused else 0)
+    calls = [b - a for a, b in zip(c0, c1)]
+    print(f"serve ({'fused' if fused else 'two seams'}): {total} recognise requests, {conc} in flight: "
+          f"{total / dt:.0f} requests/s, {dt / total * 1e3:.2f} ms each; {ok} answered with the enrolled id; "
+          f"device calls: {calls[0]} embeds, {calls[1]} scans, {calls[2]} fused")
+    app.state.close()
+    return total / dt, answers
+
+
+async def main():
+    conc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    total = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    enrolled = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    ctx = Context(device=0, max_batch=256)
+    ctx.load_model(pack_blob(synthetic_weights(seed=0xFACE)), input_scale=1.0 / 16.0)
+    rng = np.random.default_rng(5)
+    faces = [b64_jpeg(synth.crop(rng, int(rng.integers(160, 400)), int(rng.integers(160, 400)))) for _ in range(enrolled)]
+    r_seams, a_seams = await run(ctx, False, conc, total, faces)
+    r_fused, a_fused = await run(ctx, True, conc, total, faces)
+    same = sum(a_seams[i] == a_fused[i] for i in range(total))
+    print(f"fused / two seams = {r_fused / r_seams:.2f}x; {same} of {total} answers identical")
     ctx.close()
 
 

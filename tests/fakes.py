@@ -62,3 +62,18 @@ class HashEmbedder:
         rng = np.random.default_rng(int.from_bytes(h[:8], "little"))
         v = rng.standard_normal(self.dim).astype(np.float32)
         return v / np.linalg.norm(v)
+
+
+class FakeContext:
+    """Stand-in for frhot.engine.Context.recognise: HashEmbedder descriptors searched in a NumpyGallery."""
+
+    def __init__(self, max_batch=16, dim=4096):
+        self.max_batch = max_batch
+        self.embedder = HashEmbedder(dim)
+        self.calls = []
+
+    def recognise(self, gallery, images, qkeys=None, k=5, gamma=False, flip=True, want_embeddings=False):
+        self.calls.append(len(images))
+        emb = np.stack([self.embedder.embed(im, gamma=gamma) for im in images])
+        s, r = gallery.search(emb, qkeys, k)
+        return s, r, (emb if want_embeddings else None)

@@ -569,7 +569,8 @@ def test_gallery_write_f16_restores_bit_for_bit(gpu_ctx, tmp_path):
     svc2.close()
 
 
-def test_api_end_to_end_concurrent_requests(gpu_ctx):
+@pytest.mark.parametrize("fused", [False, True])
+def test_api_end_to_end_concurrent_requests(gpu_ctx, fused):
     """The two routes served from the GPU context (frhot.api.create_app): enrol, then recognise
     from many requests in flight at once.  The behaviour the reference's manual scripts exercise
     (test/register.py then test/detect.py: the enrolled picture is recognised as its id and name),
@@ -591,7 +592,7 @@ def test_api_end_to_end_concurrent_requests(gpu_ctx):
 
     rng = np.random.default_rng(77)
     people = [b64(synth.crop(rng, int(rng.integers(120, 300)), int(rng.integers(120, 300)))) for _ in range(12)]
-    app = create_app(gpu_ctx, capacity=256, api_key="k", max_delay_s=0.05)
+    app = create_app(gpu_ctx, capacity=256, api_key="k", max_delay_s=0.05, fused=fused)
     H = {"X-API-Key": "k"}
 
     async def run():
@@ -606,12 +607,17 @@ def test_api_end_to_end_concurrent_requests(gpu_ctx):
                 "img_base64": people[0], "id": "999", "name": "Dup", "role": "1", "store_id": "S"})
             assert r.status_code == 409
             b0, s0 = app.state.batcher.batches, app.state.search_batcher.batches
+            f0 = app.state.recogniser.batches if fused else 0
             rs = await asyncio.gather(*[c.post("/face_recog_img_base64", headers=H, json={
                 "img_base64": img, "role": "1", "store_id": "S"}) for img in people])
             for i, r in enumerate(rs):
                 assert r.status_code == 200 and r.json() == {"status": 1, "id": str(100 + i), "name": f"P{i}"}, r.text
-            assert app.state.batcher.batches - b0 < len(people)            # crops shared device calls
-            assert app.state.search_batcher.batches - s0 < len(people)     # and so did the searches
+            if fused:
+                assert app.state.recogniser.batches - f0 < len(people)         # requests shared fused device calls
+                assert app.state.batcher.batches == b0 and app.state.search_batcher.batches == s0
+            else:
+                assert app.state.batcher.batches - b0 < len(people)            # crops shared device calls
+                assert app.state.search_batcher.batches - s0 < len(people)     # and so did the searches
             r = await c.post("/face_recog_img_base64", headers=H, json={"img_base64": people[0], "role": "0", "store_id": "S"})
             assert r.status_code == 404                                    # nothing enrolled among the customers
             r = await c.post("/face_recog_img_base64", json={"img_base64": people[0], "role": "1", "store_id": "S"})
@@ -619,11 +625,7 @@ def test_api_end_to_end_concurrent_requests(gpu_ctx):
     try:
         asyncio.run(run())
     finally:
-        app.state.batcher.close()
-        app.state.search_batcher.close()
-        app.state.gallery_service.close()
-        from frhot import legacy
-        legacy.install_engine(None)
+        app.state.close()
 
 
 def test_sharded_search_exchange_path_on_rccl(gpu_ctx):

@@ -144,7 +144,7 @@ def test_threshold_and_vote_decide_on_the_gpu(disc_ctx):
     import httpx
     from PIL import Image
 
-    from frhot import legacy, synth
+    from frhot import synth
     from frhot.api import create_app
     ctx, _w = disc_ctx
 
@@ -179,7 +179,4 @@ def test_threshold_and_vote_decide_on_the_gpu(disc_ctx):
     try:
         asyncio.run(run())
     finally:
-        app.state.batcher.close()
-        app.state.search_batcher.close()
-        app.state.gallery_service.close()
-        legacy.install_engine(None)
+        app.state.close()

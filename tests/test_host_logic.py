@@ -182,21 +182,31 @@ def _b64(img):
     return base64.b64encode(buf.getvalue()).decode()
 
 
-@pytest.fixture()
-def client():
+@pytest.fixture(params=["seams", "fused"])
+def client(request):
+    """The two routes over CPU stand-ins, served through the two seams (get_embedding + search_point)
+    and through the fused step (RecogniseBatcher -> GalleryService.recognise_points)."""
     from fastapi import FastAPI
     from fastapi.testclient import TestClient
+    from fakes import FakeContext
     from frhot import legacy
     from frhot.api import build_router
+    from frhot.batcher import RecogniseBatcher
     from frhot.database_client import DatabaseClient
     from frhot.face_service import FaceService
     legacy.install_engine(HashEmbedder())
     svc = _service(4096, 64)
+    recogniser = None
+    if request.param == "fused":
+        svc.gallery.ctx = FakeContext()
+        recogniser = RecogniseBatcher(svc, 16, max_delay_s=0.005)
     app = FastAPI()
-    app.include_router(build_router(FaceService(DatabaseClient(svc)), api_key="k"))
+    app.include_router(build_router(FaceService(DatabaseClient(svc), recogniser=recogniser, max_in_flight=16), api_key="k"))
     with TestClient(app) as c:
         c.svc = svc
         yield c
+    if recogniser is not None:
+        recogniser.close()
     legacy.install_engine(None)
 
 
@@ -518,3 +528,44 @@ def test_failed_writes_leak_no_rows_and_keep_the_live_collection(tmp_path):
     # a snapshot larger than the gallery is refused before anything is dropped
     small = _service(8, 4)
     assert small.recover_snapshot("S_Employees", path)[0] == 404 and small.point_count("S_Employees") == 0
+
+
+def test_recognise_batcher_groups_and_isolates_failures():
+    """Requests in flight together share one fused call; a crop the library refuses fails alone."""
+    from fakes import FakeContext
+    from frhot.batcher import RecogniseBatcher
+    svc = _service(4096, 64)
+    ctx = FakeContext(max_batch=8)
+    svc.gallery.ctx = ctx
+    svc.create_collection("S_Employees")
+    crops = [np.full((6, 6, 3), i, np.uint8) for i in range(5)]
+    for i in range(3):
+        emb = ctx.embedder.embed(crops[i], gamma=True)
+        assert svc.insert_point("S_Employees", emb, f"p{i}", f"n{i}", "S")[0] == 201
+    real = ctx.recognise
+
+    def picky(gallery, images, *a, **k):
+        if any(im[0, 0, 0] == 4 for im in images):
+            raise RuntimeError("frhot error -1: bad crop")
+        return real(gallery, images, *a, **k)
+
+    ctx.recognise = picky
+    b = RecogniseBatcher(svc, 8, max_delay_s=0.2)
+    futs = [b.submit("S_Employees", crops[i], "S", want_embedding=(i == 1)) for i in range(5)]
+    futs.append(b.submit("S_Employees", np.zeros((1, 400, 3), np.uint8), "S"))
+    futs.append(b.submit("nope", crops[0], "S"))
+    res = []
+    for f in futs:
+        try:
+            res.append(f.result(timeout=10))
+        except Exception as e:
+            res.append(type(e).__name__)
+    b.close()
+    for i in range(3):
+        st, content, emb = res[i]
+        assert st == 200 and content["message"] == "Point found" and content["data"][0][1]["id"] == f"p{i}"
+        assert (emb is not None) == (i == 1)
+    assert res[3][:2] == (200, {"message": "Point not found", "data": []})
+    assert res[4] == "RuntimeError" and res[5] == "ValueError"
+    assert res[6][0] == 404
+    assert ctx.calls == [1] * 5          # the refused group call, then one call per request (the refused one records nothing)
