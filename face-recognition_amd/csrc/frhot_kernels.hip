@@ -27,7 +27,12 @@
 
 namespace frhot {
 
-#if FR_DBG & (8 | 32)
+#if FR_DBG & 64
+// scan diagnosis, per block (wave 0): {entry, loop begin, loop end, exit, cycles inside tile ends, tile ends,
+// insertion rounds, cycles before the per-group work, in the per-group preludes, in the insertion loops}
+__device__ unsigned long long g_scan_stamp[256 * 16];
+#endif
+#if FR_DBG & (8 | 32 | 64)
 __device__ unsigned long long g_stamp[64];
 #define FR_STAMP(var)                                                                        \
     do {                                                                                     \
@@ -58,6 +63,41 @@ FR_DEV void glds16(const void* g, void* lds_wave_base) {
 FR_DEV void glds16_nt(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
+// LDS accesses written as the instructions themselves.  The compiler orders every LDS access
+// it emits behind ALL LDS-DMA in flight (s_waitcnt vmcnt(0)): it cannot tell that a small table
+// beside the rings is never a DMA target.  These helpers keep the ring's prefetch in flight.
+FR_DEV unsigned lds_offset(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+FR_DEV void lds_max_u32(unsigned addr, unsigned v) {
+    asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// min of the first K of N4*4 consecutive words at addr (16-byte aligned); waits for its own reads
+template <int N4, int K>
+FR_DEV unsigned lds_min_words(unsigned addr) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 v[N4];
+    if constexpr (N4 == 2)
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(addr) : "memory");
+    else if constexpr (N4 == 3)
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(addr) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                     "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
+    static_assert(N4 >= 2 && N4 <= 4 && K <= N4 * 4, "slot words");
+    unsigned m = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < N4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i * 4 + j < K) m = v[i][j] < m ? v[i][j] : m;
+    return m;
 }
 
 FR_DEV uint64_t splitmix64(uint64_t x) {
@@ -1354,6 +1394,10 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     // loads that may stay in flight at the end of a step (see the wait below)
     constexpr int INFLIGHT = (DX == 3 && DY == 2) ? 2 * NPX + NPY : (DX == 2 && DY == 2) ? NPX + NPY : NPX;
     static_assert((DX == 3 && DY == 2) || (DX == 2 && DY == 2) || (DX == 2 && DY == 1), "ring depths");
+    // Block-level score bounds in LDS for the HBM-bound 64-query tile (see the tile end below):
+    // KP words per query, of which K are slots.
+    constexpr bool LB = RY <= 64;
+    constexpr int KP = (K + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs = smem;
     char* const ys = smem + XS * XB;
@@ -1361,6 +1405,11 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = wave / WY, wy = wave % WY;
     const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+#if FR_DBG & 64
+    unsigned long long sc_t0 = 0, sc_t1 = 0, sc_t2 = 0, sc_t3 = 0, sc_sel = 0, sc_ta = 0, sc_tb = 0, sc_n = 0, sc_it = 0;
+    unsigned long long sc_tc = 0, sc_td = 0, sc_pre = 0, sc_prel = 0, sc_loop = 0;
+    FR_STAMP(sc_t0);
+#endif
     const int qtiles = gridDim.x / nb;
     const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
     const int qt = seq % qtiles, gb = (seq / qtiles) * 8 + xcd;
@@ -1426,6 +1475,10 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
+        if constexpr (LB) {
+            unsigned* const lb = (unsigned*)(smem + XS * XB + YS * YB);      // [RY][KP]
+            for (int i = tid; i < RY * KP; i += 512) lb[i] = 0u;
+        }
         // prologue: the first DY query slices and DX gallery steps; everything lands before phase 0
 #pragma unroll
         for (int i = 0; i < DY; ++i)
@@ -1433,8 +1486,17 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #pragma unroll
         for (int i = 0; i < DX; ++i)
             if (i < S) issue_x(i);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#if FR_DBG & 64
+        FR_STAMP(sc_t1);
+#endif
+        // block-level bound per query column group (-inf: none yet); byte offset of the lane's
+        // slot row in LDS
+        float lbval[LB ? NY : 1];
+#pragma unroll
+        for (int y = 0; y < (LB ? NY : 1); ++y) lbval[y] = -INFINITY;
+        const unsigned lbrow = lds_offset(smem + XS * XB + YS * YB) + (unsigned)((wy * TY + l15) * KP * 4);
 
         // A step runs as NUN units u = (kk, xh): kk = 32-deep half of the step, xh = 1/XSPLIT of the
         // gallery rows.  The query fragments of a kk are read with its first unit and kept; the large
@@ -1487,6 +1549,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                 unit(std::integral_constant<int, 3>{});
             }
             if (ks == nk - 1) {
+#if FR_DBG & 64
+                FR_STAMP(sc_ta);
+#endif
                 const int rbase = (int)(tile * 256) + wx * TX + g0 * 4;     // rows fit 31 bits (checked at launch)
                 // Rows whose key does not match the query's, and rows past the end of the gallery (last
                 // tile only), are struck out of the accumulators in place (the next tile starts
@@ -1507,7 +1572,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         mq = max3_raw(mq, a[x][0], a[x][1]);
                         mq = max3_raw(mq, a[x][2], a[x][3]);
                     }
-                    some = some || __any(mq > top[y].s[K - 1]);
+                    some = some || (LB ? __any(mq > top[y].s[K - 1] && mq >= lbval[LB ? y : 0]) : __any(mq > top[y].s[K - 1]));
                 }
                 if (some) {
                 if (USE_KEYS) {
@@ -1546,11 +1611,55 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                             for (int j = 0; j < 4; ++j)
                                 acc[y][x][j] = (rbase + x * 16 + j < nr) ? acc[y][x][j] : -INFINITY;
                 }
+                }   // some
+                // Block-level bound (64-query tile).  A lane's list sees 1/(4*WX) of the block's rows,
+                // so while the lists fill nearly every score beats its lane's tail and is inserted:
+                // on a 1 M-row gallery a quarter of the launch went into those insertions.  The block
+                // keeps K slots per query in LDS; each of the 4*WX lists of a query belongs to one slot
+                // (list number mod K) and raises it (LDS atomic max) to the best score its lane has
+                // seen, this tile included.  The lists cover disjoint rows, so the slots' minimum is a
+                // lower bound on the query's K-th best score over everything the BLOCK has scanned:
+                // scores below it are not inserted (scores equal to it are: ties are ordered by row).
+                // With the barrier between raising and reading, the first tile is already filtered by
+                // the K-th best of its own 4*WX lane maxima.  Stale slots only weaken the bound.
+                if constexpr (LB) {
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        const float4v (&a)[NX] = acc[y];
+                        float mq = max3_raw(a[0][0], a[0][1], a[0][2]);
+                        mq = max3_raw(mq, a[0][3], a[0][3]);
+#pragma unroll
+                        for (int x = 1; x < NX; ++x) {
+                            mq = max3_raw(mq, a[x][0], a[x][1]);
+                            mq = max3_raw(mq, a[x][2], a[x][3]);
+                        }
+                        mq = some ? fmaxf(mq, top[y].s[0]) : top[y].s[0];     // keyed scan without candidates: raw scores do not count
+                        const unsigned hk = ordered_key(mq);
+                        if (hk > ordered_key(-INFINITY))
+                            lds_max_u32(lbrow + (unsigned)((y * 16 * KP + (wx * 4 + g0) % K) * 4), hk);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        const unsigned bm = lds_min_words<KP / 4, K>(lbrow + (unsigned)(y * 16 * KP * 4));
+                        lbval[y] = bm > 1u ? ordered_value(bm) : -INFINITY;     // 0: some slot is still empty
+                    }
+                }
+#if FR_DBG & 64
+                FR_STAMP(sc_tc);
+                sc_pre += sc_tc - sc_ta;
+#endif
+                if (some) {
 #pragma unroll
                 for (int y = 0; y < NY; ++y) {
                     // one query column group at a time: interleaving the groups would need their
                     // temporaries live together, beside 128 accumulators and the lists
                     __builtin_amdgcn_sched_barrier(0);
+#if FR_DBG & 64
+                    FR_STAMP(sc_tc);
+#endif
                     // The common case once the lists' tails carry a good bound: no lane's best of its
                     // 4*NX scores beats its own tail.  One three-input max per two scores.
                     {
@@ -1562,7 +1671,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                             mq = max3_raw(mq, a[x][0], a[x][1]);
                             mq = max3_raw(mq, a[x][2], a[x][3]);
                         }
-                        if (!__any(mq > top[y].s[K - 1])) continue;
+                        if (LB ? !__any(mq > top[y].s[K - 1] && mq >= lbval[LB ? y : 0]) : !__any(mq > top[y].s[K - 1])) continue;
                     }
                     // Lower bounds on the K-th best score of the query over the four lanes' lists:
                     // (a) any lane's own K-th best; (b) min(best (KA+1)-th of any lane, worst
@@ -1572,6 +1681,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                     static_assert(KA >= KB && KA < K && (KA + 1) + 3 * (KB + 1) >= K, "threshold bound");
                     float thr = lanes4_max(top[y].s[K - 1]);
                     thr = fmaxf(thr, fminf(lanes4_max(top[y].s[KA]), lanes4_min(top[y].s[KB])));
+                    if constexpr (LB) thr = fmaxf(thr, lbval[LB ? y : 0]);
                     float4v (&v)[NX] = acc[y];        // struck-out entries may be overwritten: the next tile starts from zero
                     // best and second best of the lane's 4*NX scores, branch-free
                     float m1 = -INFINITY, m2 = -INFINITY;
@@ -1620,11 +1730,18 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         continue;
                     }
                     float m = m1;
+#if FR_DBG & 64
+                    FR_STAMP(sc_td);
+                    sc_prel += sc_td - sc_tc;
+#endif
                     // Long lists, taken while any lane still holds a score that belongs in its list:
                     // each lane inserts its best remaining score (equal scores: lowest row first, the
                     // order the list expects), strikes it out and looks for the next.  The cost follows
                     // the number of real candidates per lane, not the tile's 4*NX scores.
                     while (__any(m >= thr && m > top[y].s[K - 1])) {
+#if FR_DBG & 64
+                        ++sc_it;
+#endif
                         const bool want = m >= thr && m > top[y].s[K - 1];
                         int hit = -1;
 #pragma unroll
@@ -1643,6 +1760,10 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                             }
                         m = want ? m2 : -INFINITY;     // a lane with nothing to insert is done with this tile
                     }
+#if FR_DBG & 64
+                    FR_STAMP(sc_tc);
+                    sc_loop += sc_tc - sc_td;
+#endif
                 }
                 }   // some
                 // Cross-block bound.  A lane's list sees 1/(4*WX*nb) of the rows, so its own K-th best
@@ -1698,6 +1819,10 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                     }
                 }
                 ks = 0; tile += nb;
+#if FR_DBG & 64
+                FR_STAMP(sc_tb);
+                sc_sel += sc_tb - sc_ta; ++sc_n;
+#endif
             } else {
                 ++ks;
             }
@@ -1713,6 +1838,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         }
     }
 
+#if FR_DBG & 64
+    FR_STAMP(sc_t2);
+#endif
     // merge the WX*4 lists of each query through LDS
     constexpr int NL = WX * 4;
     __syncthreads();
@@ -1764,6 +1892,14 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
             }
         }
     }
+#if FR_DBG & 64
+    FR_STAMP(sc_t3);
+    if (tid == 0 && blockIdx.x < 256) {
+        unsigned long long* const o = g_scan_stamp + blockIdx.x * 16;
+        o[0] = sc_t0; o[1] = sc_t1; o[2] = sc_t2; o[3] = sc_t3; o[4] = sc_sel; o[5] = sc_n; o[6] = sc_it;
+        o[7] = sc_pre; o[8] = sc_prel; o[9] = sc_loop;
+    }
+#endif
 }
 
 // Wave-wide unsigned max / min through DPP row shifts and row broadcasts: no LDS traffic, the
@@ -2033,6 +2169,12 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStr
     return hipSuccess;
 }
 
+#if FR_DBG & 64
+hipError_t scan_debug_stamps(unsigned long long* out) {      // 256 x 16 values of the last scan launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_stamp), sizeof(unsigned long long) * 256 * 16);
+}
+#endif
+
 int scan_max_blocks() { return 256; }
 
 static int scan_klist(int k) { return k <= 5 ? 5 : (k <= 10 ? 10 : 16); }
@@ -2110,7 +2252,8 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
                             int Bq, int nb, float* part_s, int64_t* part_r, unsigned* qbound, hipStream_t s,
                             bool attr_only) {
     constexpr int xs = RY <= 64 ? 4 : 3, ys = RY <= 128 ? 3 : 2;
-    constexpr int ring = xs * 256 * 128 + ys * RY * 128;
+    constexpr int bounds = RY <= 64 ? RY * ((K + 3) & ~3) * 4 : 0;        // block-level score bounds
+    constexpr int ring = xs * 256 * 128 + ys * RY * 128 + bounds;
     constexpr int merge = RY * WX * 4 * K * 8;
     constexpr int lds = ring > merge ? ring : merge;
     static_assert(lds <= 160 * 1024, "LDS budget");

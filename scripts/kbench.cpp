@@ -17,6 +17,10 @@ using namespace frhot;
 #if FR_DBG & (8 | 32)
 namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
 #endif
+#if FR_DBG & 64
+namespace frhot { hipError_t scan_debug_stamps(unsigned long long* out); }
+#include <algorithm>
+#endif
 
 #define CK(x)                                                                                  \
     do {                                                                                       \
@@ -96,7 +100,7 @@ static void bench_conv(int B) {
         CK(hipMemset(bias, 0, 64 * 4));
         void* y;
         CK(hipMalloc(&y, (size_t)B * 226 * 226 * 64 * 2));
-        const float ms = time_ms([&] { CK(launch_conv1_1(x0, w, bias, y, B, s)); }, 2, 10, s);
+        const float ms = time_ms([&] { CK(launch_conv1_1(x0, w, bias, y, B, s)); }, 3, 40, s);
         const double bytes = (double)B * 224 * 224 * 64 * 2;
         printf("%-10s %8.3f ms  store %7.1f GB/s\n", "conv1_1", ms, bytes / ms / 1e6);
         tot_ms += ms;
@@ -116,7 +120,7 @@ static void bench_conv(int B) {
         void* y;
         CK(hipMalloc(&y, yout * 2));
         CK(hipMemset(y, 0, yout * 2));
-        const float ms = time_ms([&] { CK(launch_conv3x3(d, x, w, bias, y, dump, B, s)); }, 2, 10, s);
+        const float ms = time_ms([&] { CK(launch_conv3x3(d, x, w, bias, y, dump, B, s)); }, 3, 40, s);
         const double fl = 2.0 * B * d.hw * d.hw * 9.0 * d.cin * d.cout;
         const int reps = (i == 9) ? 2 : 1;
         printf("%-10s %8.3f ms  %7.1f TFLOP/s   (hw %d cin %d cout %d pool %d)\n", names[i], ms, fl / ms / 1e9,
@@ -181,16 +185,39 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
     if (!getenv("KBENCH_NO_BOUND")) CK(hipMalloc((void**)&qb, scan_bound_bytes(Bq)));
     int nblk = 0;
     const float ms = time_ms(
-        [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, qb, &nblk, s)); }, 2, 10, s);
+        [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, qb, &nblk, s)); }, 3, 40, s);
     const double bytes = (double)N * D * 2 + (use_keys ? (double)N * 4 : 0.0) + (double)Bq * D * 2;
     const double fl = 2.0 * Bq * (double)N * D;
     float* os;
     int64_t* orr;
     CK(hipMalloc((void**)&os, (size_t)Bq * k * 4));
     CK(hipMalloc((void**)&orr, (size_t)Bq * k * 8));
-    const float ms_final = time_ms([&] { CK(launch_topk_final(ps, pr, nblk, kl, Bq, k, 0, os, orr, s)); }, 2, 10, s);
+    const float ms_final = time_ms([&] { CK(launch_topk_final(ps, pr, nblk, kl, Bq, k, 0, os, orr, s)); }, 3, 40, s);
     printf("scan N=%-9ld D=%-4d Bq=%-4d k=%-2d keys=%d  %8.3f ms  %7.1f GB/s (%.2f of 8 TB/s)  %7.1f TFLOP/s  nblk %d  final merge %.3f ms\n",
            N, D, Bq, k, use_keys, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0, fl / ms / 1e9, nblk, ms_final);
+#if FR_DBG & 64
+    {
+        CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, qb, &nblk, s));
+        CK(hipStreamSynchronize(s));
+        static unsigned long long st[256 * 16];
+        CK(frhot::scan_debug_stamps(st));
+        const int nbk = nblk < 256 ? nblk : 256;
+        std::vector<double> col[10];
+        for (int b = 0; b < nbk; ++b) {
+            const unsigned long long* o = st + b * 16;
+            const double v[10] = {(double)(o[1] - o[0]), (double)(o[2] - o[1]), (double)(o[3] - o[2]), (double)o[4],
+                                  (double)o[5], (double)o[6], (double)o[7], (double)o[8], (double)o[9], 0.0};
+            for (int i = 0; i < 9; ++i) col[i].push_back(v[i]);
+        }
+        auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+        printf("   stamps (cycles, wave 0; median / max over %d blocks): prologue %.0f / %.0f  loop %.0f / %.0f  merge tail %.0f / %.0f\n"
+               "      tile ends: %.0f in all, %.0f / %.0f cycles  = before the groups %.0f + group preludes %.0f + insertion loops %.0f "
+               "(%.0f / %.0f rounds)\n",
+               nbk, med(col[0]), mx(col[0]), med(col[1]), mx(col[1]), med(col[2]), mx(col[2]), med(col[4]), med(col[3]), mx(col[3]),
+               med(col[6]), med(col[7]), med(col[8]), med(col[5]), mx(col[5]));
+    }
+#endif
     CK(hipFree(os)); CK(hipFree(orr));
     if (qb) CK(hipFree(qb));
     CK(hipFree(g)); CK(hipFree(gk)); CK(hipFree(q)); CK(hipFree(ps)); CK(hipFree(pr));
@@ -207,6 +234,16 @@ static void bench_scan() {
             bench_scan_one(n, 512, 64, 10, 0, s);
             bench_scan_one(n, 512, 256, 5, 0, s);
         }
+        CK(hipStreamDestroy(s));
+        return;
+    }
+    if (getenv("KBENCH_SHORT")) {         // the HBM-bound shape and its neighbours only
+        for (long n : {1000000L, 2000000L}) {
+            bench_scan_one(n, 512, 64, 10, 0, s);
+            bench_scan_one(n, 512, 64, 5, 0, s);
+        }
+        bench_scan_one(10000000, 512, 64, 10, 0, s);
+        bench_scan_one(10000000, 512, 256, 5, 0, s);
         CK(hipStreamDestroy(s));
         return;
     }
