@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0xFACE0000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan64", action="store_true", help="skip the secondary scan-only measurements")
+    ap.add_argument("--no-scan4096", action="store_true", help="skip the 1M x 4096 scan-only shape (profiling passes: "
+                    "it shares its kernel with the headline scan)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive (host crops in) measurement")
     ap.add_argument("--cpu-faces", type=int, default=4, help="faces the CPU baseline embeds")
     ap.add_argument("--cpu-rows", type=int, default=400_000, help="gallery rows the CPU baseline scans")
@@ -382,8 +384,9 @@ def main():
             log("scan-only shapes")
             scan64 = scan_only(ctx, Gallery, dev, 1_000_000, 512, 64, 10, args.seed + 77,
                                "BASELINE config 2 (HBM-bound)", "hbm")
-            scan4096 = scan_only(ctx, Gallery, dev, 1_000_000, 4096, 256, 5, args.seed + 78,
-                                 "BASELINE config 3 at the reference's dimension (ridge)", "hbm", iters=10)
+            if not args.no_scan4096:
+                scan4096 = scan_only(ctx, Gallery, dev, 1_000_000, 4096, 256, 5, args.seed + 78,
+                                     "BASELINE config 3 at the reference's dimension (ridge)", "hbm", iters=10)
 
         line = None
         if rank == 0:
@@ -424,7 +427,8 @@ def main():
                 line["pcie_inclusive"] = host_leg
             if scan64 is not None:
                 line["roofline_scan_hbm"] = scan64
-                line["roofline_scan_d4096"] = scan4096
+                if scan4096 is not None:
+                    line["roofline_scan_d4096"] = scan4096
             if P == 1 and not rehearse and not args.no_cpu_baseline:
                 log("cpu baseline")
                 base, gates = cpu_baseline(ctx, gal, images, args, rows_local)

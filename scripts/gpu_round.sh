@@ -7,13 +7,13 @@ tag=${1:-run}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$out/tests.log" 2>&1 || { tail -30 "$out/tests.log"; exit 1; }
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > "$out/tests.log" 2>&1 || { tail -30 "$out/tests.log"; exit 1; }
 tail -3 "$out/tests.log"
 timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1 || { tail -30 "$out/smoke.log"; exit 1; }
 tail -1 "$out/smoke.log"
 timeout -k 10 400 python -u bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
 cat "$out/bench.json"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$out/trace.log" 2>&1 || { tail -30 "$out/trace.log"; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 > "$out/trace.log" 2>&1 || { tail -30 "$out/trace.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }
 find "$out" -name '*kernel_stats.csv' | head -1 | xargs cat
