@@ -761,8 +761,10 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = wave / WY, wy = wave % WY;
     const int l15 = lane & 15, g0 = lane >> 4;
-    const long M = (long)batch * H * W;
-    const long ntiles = ((M + 255) / 256) * NT;
+    // pixel indices fit an int: the launcher bounds the input to 4 GiB of 32-bit byte offsets.
+    // (As 64-bit values the divisions below cost registers that the pooled variants spilled.)
+    const int M = batch * H * W;
+    const long ntiles = (long)((M + 255) / 256) * NT;
     const int G = gridDim.x;
     const int wk = xcd_remap(blockIdx.x, G);
     const long my_tiles = wk < ntiles ? (ntiles - wk + G - 1) / G : 0;
@@ -777,16 +779,16 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     // `reverse` walks the pixel tiles from the last image to the first: a layer then starts on
     // the part of its input that the previous layer wrote last and that the 256 MiB Infinity
     // Cache still holds (layers alternate direction)
-    const long nmt = (M + 255) / 256;
+    const int nmt = (M + 255) / 256;
     auto set_pixels = [&](long tile) {
-        const long mt = tile / NT;
-        const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
+        const int mt = (int)(tile / NT);
+        const int m0 = (reverse ? nmt - 1 - mt : mt) * 256;
 #pragma unroll
         for (int i = 0; i < Core::NPX; ++i) {
-            long m = m0 + Core::stage_row(wave, lane, i);
+            int m = m0 + Core::stage_row(wave, lane, i);
             m = m < M ? m : M - 1;
-            const int b = (int)(m / (H * W));
-            const int rem = (int)(m % (H * W));
+            const int b = m / (H * W);
+            const int rem = m % (H * W);
             const int win = rem >> 2, d = rem & 3;
             const int py = 2 * (win / HALF) + (d >> 1), px = 2 * (win % HALF) + (d & 1);
             xo[i] = (unsigned)(((((long)b * (H + 2) + py) * PW + px) * CIN) * 2 + cb);
@@ -860,15 +862,15 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
     long tile = wk;
     // epilogue of the tile whose last step has just been accumulated
     auto epilogue = [&]() __attribute__((always_inline)) {
-        const long mt = tile / NT;
-        const long m0 = (reverse ? nmt - 1 - mt : mt) * 256;
+        const int mt = (int)(tile / NT);
+        const int m0 = (reverse ? nmt - 1 - mt : mt) * 256;
 #pragma unroll
         for (int px = 0; px < NX; ++px) {
-            const long m = m0 + wx * Core::TX + px * 16 + l15;
+            const int m = m0 + wx * Core::TX + px * 16 + l15;
             const bool live = m < M;
-            const long mm = live ? m : M - 1;
-            const int b = (int)(mm / (H * W));
-            const int rem = (int)(mm % (H * W));
+            const int mm = live ? m : M - 1;
+            const int b = mm / (H * W);
+            const int rem = mm % (H * W);
             const int win = rem >> 2, d = rem & 3;
             int oy, ox;
             if (POOL) { oy = win / HALF; ox = win % HALF; }
@@ -884,10 +886,13 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
                     if (POOL) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
+                            // max over the 2x2 window = the four lanes of a quad (row-local DPP; a
+                            // shuffle intrinsic compiles to ds_bpermute here, 512 LDS-path ops per tile)
                             float t = v[j];
-                            t = fmaxf(t, __shfl_xor(t, 1));
-                            t = fmaxf(t, __shfl_xor(t, 2));
-                            v[j] = t;
+                            int q = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true);
+                            t = fmaxf(t, __builtin_bit_cast(float, q));
+                            q = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true);
+                            v[j] = fmaxf(t, __builtin_bit_cast(float, q));
                         }
                     }
 #pragma unroll
