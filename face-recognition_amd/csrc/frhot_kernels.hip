@@ -464,6 +464,18 @@ __global__ __launch_bounds__(256) void normalize_pack_kernel(const uint8_t* __re
 }
 
 // --------------------------------------------------------------- gallery ---
+// Gallery rows are kept in HBM in the order the scan streams them: tile by tile (256 rows), and
+// inside a tile 64-component chunk by chunk, so that one K-step's operand (256 rows x 64
+// components = 32 KiB) is ONE contiguous block and every 1 KiB LDS-DMA piece reads 1 KiB of
+// consecutive bytes.  Row-major, a piece gathered eight 128-B lines that lay D*2 bytes apart:
+// at D = 4096 the 64-query scan streamed 5.3 TB/s that way and streams 6.6 TB/s this way.
+//   component c of row r  ->  half index ((r / 256 * (D/64) + c / 64) * 256 + r % 256) * 64 + c % 64
+// Only the kernels of this section and the scan know the layout; rows enter and leave the
+// library row-major.
+FR_DEV size_t gal_index(int64_t r, int c, int nk) {
+    return ((((size_t)(r >> 8) * (size_t)nk + (size_t)(c >> 6)) << 8) + (size_t)(r & 255)) * 64 + (size_t)(c & 63);
+}
+
 // One wave per row: normalise an f32 row and store it as fp16.
 __global__ __launch_bounds__(256) void gallery_upsert_kernel(const float* __restrict__ vecs,
                                                              const int32_t* __restrict__ keys,
@@ -483,8 +495,7 @@ __global__ __launch_bounds__(256) void gallery_upsert_kernel(const float* __rest
     float nrm = (float)sqrt(ss);
     nrm = nrm < 1e-30f ? 1.0f : nrm;
     const int64_t r = rows ? rows[i] : i;
-    half_t* dst = g + (size_t)r * D;
-    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fdiv_rn(v[c], nrm);
+    for (int c = lane; c < D; c += 64) g[gal_index(r, c, D >> 6)] = (half_t)__fdiv_rn(v[c], nrm);
     if (lane == 0 && gk) gk[r] = keys ? keys[i] : 0;
 }
 
@@ -519,8 +530,8 @@ __global__ __launch_bounds__(256) void gallery_fill_kernel(half_t* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float nrm = __fsqrt_rn((float)ss);
     const float inv = ss == 0 ? 1.0f : __fdiv_rn(1.0f, nrm);
-    half_t* dst = g + (size_t)r * D;
-    for (int c = lane; c < D; c += 64) dst[c] = (half_t)__fmul_rn((float)synth_value(seed, src, D, c), inv);
+    for (int c = lane; c < D; c += 64)
+        g[gal_index(r, c, D >> 6)] = (half_t)__fmul_rn((float)synth_value(seed, src, D, c), inv);
     if (lane == 0) gk[r] = nkeys > 0 ? (int32_t)(splitmix64(seed ^ (src * 0xD1B54A32D192ED03ull)) % (uint64_t)nkeys) : 0;
 }
 
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(256) void gallery_gather_kernel(const half_t* __res
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const int64_t r = rows[i];
-    for (int c = lane; c < D; c += 64) out[(size_t)i * D + c] = g[(size_t)r * D + c];
+    for (int c = lane; c < D; c += 64) out[(size_t)i * D + c] = g[gal_index(r, c, D >> 6)];
     if (lane == 0 && out_keys) out_keys[i] = gk[r];
 }
 
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(256) void gallery_scatter_kernel(const half_t* __re
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const int64_t r = rows[i];
-    for (int c = lane * 8; c < D; c += 512) *(half8*)(g + (size_t)r * D + c) = *(const half8*)(in + (size_t)i * D + c);
+    for (int c = lane * 8; c < D; c += 512) *(half8*)(g + gal_index(r, c, D >> 6)) = *(const half8*)(in + (size_t)i * D + c);
     if (lane == 0) gk[r] = in_keys[i];
 }
 
@@ -1425,11 +1436,13 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     const long S = my_tiles * nk;
     const int cb = ((l7 ^ (lane >> 3)) << 4);
 
-    // Per-lane byte offsets of this lane's 16 B inside a gallery tile / the query block (the host
-    // checks that both stay below 4 GiB).  Piece i of a stage is 64 rows further on, a uniform
-    // distance that goes into the scalar part of the address, so one register serves all pieces;
-    // query rows past Bq are clamped to the last row (their columns are never written out).
+    // Per-lane byte offsets of this lane's 16 B inside the query block (row-major; the host checks
+    // that it stays below 4 GiB).  Piece i of a stage is 64 rows further on, a uniform distance that
+    // goes into the scalar part of the address, so one register serves all pieces; query rows past
+    // Bq are clamped to the last row (their columns are never written out).
     const unsigned xo0 = (unsigned)((8 * wave + (lane >> 3)) * D * 2 + cb);
+    // inside a gallery K-step block (256 rows x 128 B, contiguous: see gal_index) the same lane's 16 B
+    const unsigned xg0 = (unsigned)((8 * wave + (lane >> 3)) * 128 + cb);
     // the query block's offsets are the gallery tile's plus the query tile's first row (a uniform
     // term): they are rebuilt from xo0 at every use instead of occupying a register of their own
     const unsigned yq0 = (unsigned)q0 * (unsigned)D * 2u;
@@ -1449,15 +1462,15 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         long itile = gb; int iks = 0;   // next gallery step to issue
         int yks = 0;                    // next query slice to issue
         auto issue_x = [&](int slot) __attribute__((always_inline)) {
-            const char* const base = (const char*)gal + ((size_t)itile * 256 * D + (size_t)iks * 64) * 2;
+            const char* const base = (const char*)gal + ((size_t)itile * nk + (size_t)iks) * 32768;
 #pragma unroll
             // with one query tile every gallery byte is read by one CU, once: stream it non-temporally
             // (+3..6 % on the HBM-bound shapes); with several, the other tiles' blocks want it in L2
             for (int i = 0; i < NPX; ++i) {
-                unsigned o = xo0;
+                unsigned o = xg0;
                 asm volatile("" : "+v"(o));     // keeps the 64-bit sum out of loop-invariant registers
-                if (qtiles == 1) glds16_nt(base + (size_t)i * pstride + o, xs + slot * XB + (wave + 8 * i) * 1024);
-                else glds16(base + (size_t)i * pstride + o, xs + slot * XB + (wave + 8 * i) * 1024);
+                if (qtiles == 1) glds16_nt(base + (size_t)i * 8192 + o, xs + slot * XB + (wave + 8 * i) * 1024);
+                else glds16(base + (size_t)i * 8192 + o, xs + slot * XB + (wave + 8 * i) * 1024);
             }
             if (++iks == nk) { iks = 0; itile += nb; }
         };

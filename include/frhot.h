@@ -113,7 +113,8 @@ int frhot_embed_dev(frhot_ctx* ctx, const void* crops_dev, const int64_t* offset
 int frhot_debug_read(frhot_ctx* ctx, int stage, int B, void* host_out, size_t nbytes);
 
 /*
- * Gallery = device-resident [capacity, D] fp16 unit rows + int32 key per row.
+ * Gallery = device-resident fp16 unit rows ([capacity, D]; kept in HBM in a tiled order private to
+ * the library, rows cross this interface row-major) + int32 key per row.
  * A key stands for the reference's collection name f"{store_id}_Employees" /
  * f"{store_id}_Customers" (app/src/services/face_service.py:355-360), which
  * also subsumes the store_id payload filter of qdrant_database_FE/app.py:320-327.

@@ -237,6 +237,12 @@ static void bench_scan() {
         CK(hipStreamDestroy(s));
         return;
     }
+    if (getenv("KBENCH_D4096")) {         // the reference's descriptor length at serving-sized query counts
+        for (int bq : {1, 8, 64, 128, 256}) bench_scan_one(1000000, 4096, bq, 5, 0, s);
+        bench_scan_one(1000000, 4096, 64, 5, 1, s);
+        CK(hipStreamDestroy(s));
+        return;
+    }
     if (getenv("KBENCH_SHORT")) {         // the HBM-bound shape and its neighbours only
         for (long n : {1000000L, 2000000L}) {
             bench_scan_one(n, 512, 64, 10, 0, s);

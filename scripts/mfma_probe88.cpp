@@ -204,6 +204,93 @@ static void run(const _Float16* src, float* out, const char* big, size_t big_byt
            NDMA, SRC, BAR, READS, ms, fl / ms / 1e9, 256.0 * 4 * steps * NDMA * 1024 / ms / 1e6, st[0] / steps, st[0] / st[1] * 100.0);
 }
 
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// MFMA issue only (no LDS, no DMA): SHAPE 0 = 64 x v_mfma_f32_16x16x32_f16 per 32-deep half,
+// SHAPE 1 = 32 x v_mfma_f32_32x32x16_f16 (same flops, half the operand-register reads per flop)
+template <int SHAPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void probe_shape(
+    const _Float16* __restrict__ src, float* __restrict__ out, int steps) {
+    const int tid = threadIdx.x;
+    half8 fa[16], fb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        fa[i] = ((const half8*)src)[(tid * 16 + i) & 4095];
+        fb[i] = ((const half8*)src)[(tid * 16 + i + 2048) & 4095];
+    }
+    unsigned long long c0, r0, c1, r1;
+    float s = 0.f;
+    if (SHAPE == 0) {
+        float4v acc[8][8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+        for (int st = 0; st < steps; ++st) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(fa[kk * 8 + a]), "v"(fb[kk * 8 + b]));
+        }
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) s += acc[a][b][0] + acc[a][b][3];
+    } else {
+        float16v acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+        for (int st = 0; st < steps; ++st) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(fa[kq * 4 + a]), "v"(fb[kq * 4 + b]));
+        }
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s += acc[a][b][0] + acc[a][b][15];
+    }
+    if (blockIdx.x == 8 && tid == 0) { out[256 * 256] = (float)(c1 - c0); out[256 * 256 + 1] = (float)(r1 - r0); }
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int SHAPE>
+static void run_shape(const _Float16* src, float* out) {
+    const int steps = 2048;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(a));
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(probe_shape<SHAPE>, dim3(256), dim3(256), 0, 0, src, out, steps);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+    }
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= 5;
+    float st[2];
+    CK(hipMemcpy(st, out + 256 * 256, 8, hipMemcpyDeviceToHost));
+    const double fl = 256.0 * 4 * steps * 128.0 * 16 * 16 * 32 * 2;
+    printf("MFMA only, %s: %7.3f ms  %7.1f TFLOP/s  (%.0f cycles/step at %.0f MHz)\n",
+           SHAPE ? "32x32x16" : "16x16x32", ms, fl / ms / 1e9, st[0] / steps, st[0] / st[1] * 100.0);
+}
+
 int main() {
     std::vector<_Float16> h(1 << 16);
     unsigned s = 12345;
@@ -222,6 +309,10 @@ int main() {
     CK(hipMalloc((void**)&big, big_bytes));
     if (getenv("PROBE_CONST")) CK(hipMemset(big, 1, big_bytes));
     else { hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (_Float16*)big, big_bytes / 2); CK(hipDeviceSynchronize()); }
+    run_shape<0>(src, out);
+    run_shape<1>(src, out);
+    run_shape<0>(src, out);
+    run_shape<1>(src, out);
     run<16, 2, 4>(src, out, big, big_bytes);
     run<16, 2, 4, 0>(src, out, big, big_bytes);
     run<8, 2, 4>(src, out, big, big_bytes);
