@@ -154,36 +154,41 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     }, {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
 
 
-def scan_only(ctx, Gallery, dev, n, d, bq, k, seed, label, bound, iters=20):
-    """One scan-only shape on a gallery of its own, timed with the library's stream events."""
+def scan_only(ctx, Gallery, dev, n, d, seed, shapes):
+    """Scan-only shapes on one gallery of their own, timed with the library's stream events.
+    shapes: [(queries, k, label, bound, launches)]; returns one roofline object per shape."""
     gal = Gallery(ctx, d, n)
     gal.fill_synthetic(seed=seed, row0=0, n=n, nkeys=0, dup_every=0)
-    rows16, _ = gal.read(np.arange(bq) * (n // bq))
-    q = torch.from_numpy(rows16).to(dev)                    # stored rows as queries: unit fp16
-    s_out = torch.empty((bq, k), dtype=torch.float32, device=dev)
-    r_out = torch.empty((bq, k), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    for _ in range(3):
-        gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
-    ctx.timing(True)
-    for _ in range(iters):
-        gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
-    ms = ctx.stage_ms()["scan"]
-    ctx.timing(False)
-    ok = bool((r_out[:, 0].cpu().numpy() == np.arange(bq) * (n // bq)).all())
+    outs = []
+    for bq, k, label, bound, iters in shapes:
+        rows16, _ = gal.read(np.arange(bq) * (n // bq))
+        q = torch.from_numpy(rows16).to(dev)                    # stored rows as queries: unit fp16
+        s_out = torch.empty((bq, k), dtype=torch.float32, device=dev)
+        r_out = torch.empty((bq, k), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
+        ctx.timing(True)
+        for _ in range(iters):
+            gal.search_dev(q.data_ptr(), None, bq, k, s_out.data_ptr(), r_out.data_ptr(), 0)
+        ms = ctx.stage_ms()["scan"]
+        ctx.timing(False)
+        ok = bool((r_out[:, 0].cpu().numpy() == np.arange(bq) * (n // bq)).all())
+        nbytes = n * d * 2 + bq * d * 2
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        tf = 2.0 * bq * n * d / (ms * 1e-3) / 1e12
+        tr, src = pmc_traffic(n, d, bq, k)
+        outs.append({"workload": f"scan only: {n}x{d} fp16 gallery, {bq} queries, top-{k}", "bound": bound,
+                     "achieved": gbs if bound == "hbm" else tf,
+                     "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS,
+                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                     "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS,
+                     "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf,
+                     "mfma_frac": tf / MFMA_PEAK_TFLOPS, "traffic": tr, "traffic_source": src,
+                     "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms,
+                     "queries_per_s": bq / (ms * 1e-3), "top1_is_the_asked_row": ok, "label": label})
     gal.close()
-    nbytes = n * d * 2 + bq * d * 2
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    tf = 2.0 * bq * n * d / (ms * 1e-3) / 1e12
-    tr, src = pmc_traffic(n, d, bq, k)
-    out = {"workload": f"scan only: {n}x{d} fp16 gallery, {bq} queries, top-{k}", "bound": bound,
-           "achieved": gbs if bound == "hbm" else tf, "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS,
-           "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-           "frac": gbs / HBM_PEAK_GBS if bound == "hbm" else tf / MFMA_PEAK_TFLOPS,
-           "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "mfma_tflops": tf, "mfma_frac": tf / MFMA_PEAK_TFLOPS,
-           "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms,
-           "queries_per_s": bq / (ms * 1e-3), "top1_is_the_asked_row": ok, "label": label}
-    return out
+    return outs
 
 
 def pmc_traffic(rows, dim, queries, k):
@@ -379,14 +384,16 @@ def main():
                         "what": "frhot_recognise from pageable host crops, answers back on the host"}
 
         # Secondary measurements on rank 0: scan-only shapes on galleries of their own.
-        scan64 = scan4096 = None
+        scan64 = scan4096 = scan4096_q64 = None
         if rank == 0 and not args.no_scan64:
             log("scan-only shapes")
-            scan64 = scan_only(ctx, Gallery, dev, 1_000_000, 512, 64, 10, args.seed + 77,
-                               "BASELINE config 2 (HBM-bound)", "hbm")
+            scan64, = scan_only(ctx, Gallery, dev, 1_000_000, 512, args.seed + 77,
+                                [(64, 10, "BASELINE config 2 (HBM-bound)", "hbm", 20)])
             if not args.no_scan4096:
-                scan4096 = scan_only(ctx, Gallery, dev, 1_000_000, 4096, 256, 5, args.seed + 78,
-                                     "BASELINE config 3 at the reference's dimension (ridge)", "hbm", iters=10)
+                scan4096, scan4096_q64 = scan_only(
+                    ctx, Gallery, dev, 1_000_000, 4096, args.seed + 78,
+                    [(256, 5, "BASELINE config 3 at the reference's dimension (ridge)", "hbm", 10),
+                     (64, 5, "the reference's dimension at a serving-sized batch of queries (HBM-bound)", "hbm", 10)])
 
         line = None
         if rank == 0:
@@ -429,6 +436,7 @@ def main():
                 line["roofline_scan_hbm"] = scan64
                 if scan4096 is not None:
                     line["roofline_scan_d4096"] = scan4096
+                    line["roofline_scan_d4096_q64"] = scan4096_q64
             if P == 1 and not rehearse and not args.no_cpu_baseline:
                 log("cpu baseline")
                 base, gates = cpu_baseline(ctx, gal, images, args, rows_local)
