@@ -385,7 +385,7 @@ def main():
 
         # Secondary measurements on rank 0: scan-only shapes on galleries of their own.
         scan64 = scan4096 = scan4096_q64 = None
-        if rank == 0 and not args.no_scan64:
+        if P == 1 and not args.no_scan64:      # single-GPU measurements: not repeated in the scaling runs
             log("scan-only shapes")
             scan64, = scan_only(ctx, Gallery, dev, 1_000_000, 512, args.seed + 77,
                                 [(64, 10, "BASELINE config 2 (HBM-bound)", "hbm", 20)])
