@@ -150,8 +150,9 @@ def test_embed_strided_crop_views(gpu_ctx):
 
 def test_embed_full_batch(gpu_ctx, weights_f32):
     """The benchmark's batch (256 crops, several tiles per block in every layer, both tile walk
-    directions): every descriptor equals, bit for bit, the one the same crop gets in a small batch,
-    and a sample meets the cosine tolerance against the oracle."""
+    directions, full-width channel tiles in the later layers): every descriptor equals, bit for bit,
+    the one the same crop gets in a small batch (which runs those layers with the narrower channel
+    tiles of small launches), and a sample meets the cosine tolerance against the oracle."""
     from frhot import synth
     from frhot.engine import Context
     from frhot.weights import pack_blob
