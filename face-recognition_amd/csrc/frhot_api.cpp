@@ -11,7 +11,9 @@
 #include <new>
 #include <system_error>
 #include <string>
+#include <algorithm>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/frhot.h"
@@ -94,6 +96,12 @@ size_t act_elems(const LayerSpec& l, int B) {
 
 }  // namespace
 
+// Page-locked staging of one by-key search's index arrays (grown on demand, freed with its owner).
+struct IndexPin {
+    int32_t* p = nullptr;
+    size_t cap = 0;         // int32 entries
+};
+
 struct frhot_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -128,6 +136,7 @@ struct frhot_ctx {
         uint8_t* dev = nullptr; size_t dev_cap = 0;
         uint8_t* res_pin = nullptr;                  // [B,16] f32 scores, then [B,16] i64 rows
         float* emb_pin = nullptr;                    // [B,4096], allocated at the first request for descriptors
+        IndexPin idx;                                // query order / keys / tile lists of a by-key search
         hipEvent_t uploaded = nullptr, done = nullptr;
     } slot[2];
     std::atomic<unsigned> next_slot{0};
@@ -171,6 +180,22 @@ struct frhot_gallery {
     // while small, so that enrol / evict / delete calls allocate nothing
     int64_t* mut_rows = nullptr; int32_t* mut_keys = nullptr; void* mut_f16 = nullptr;
     size_t mut_cap = 0, mut_f16_cap = 0;
+    // Which 256-row tiles may hold rows of a key: ascending tile numbers per key, kept on the host
+    // under ctx->mu.  A superset is enough (rows that died or changed key stay listed; the scan
+    // still tests every row's key), so only writes add to it.  The reference keeps every collection
+    // in storage of its own and searches that alone (qdrant_database_FE/app.py:316-337); a search
+    // whose queries carry keys does the same here by scanning only its keys' tiles.
+    std::unordered_map<int32_t, std::vector<int32_t>> key_tiles;
+    bool key_tiles_valid = true;    // false: keys were written on the device (synthetic fill): read them back first
+    // Keys strewn over every tile would make the lists as large as keys x tiles and help no search:
+    // past key_tiles_limit() entries the lists are dropped for good and searches scan the whole gallery.
+    size_t key_tiles_entries = 0;
+    bool key_tiles_off = false;
+    size_t key_tiles_limit() const { return 8 * (size_t)((capacity + 255) / 256) + 65536; }
+    int search_mode = FRHOT_SEARCH_AUTO;
+    IndexPin idx;                   // of frhot_search (a call holds ctx->mu until its copies are done)
+    int32_t* idx_dev = nullptr; size_t idx_dev_cap = 0;
+    void* q16s = nullptr; size_t q16s_cap = 0;      // the queries in key order
 };
 
 namespace {
@@ -429,6 +454,203 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
     return search_launch(g, q16, qkeys_dev, Bq, k, scores_dev, rows_dev, row_base, g->part_s, g->part_r, g->qbound);
 }
 
+// ---- by-key search ---------------------------------------------------------------------------
+void key_tiles_drop(frhot_gallery* g) {
+    std::unordered_map<int32_t, std::vector<int32_t>>().swap(g->key_tiles);
+    g->key_tiles_entries = 0;
+    g->key_tiles_off = true;
+}
+
+void key_tiles_add(frhot_gallery* g, const int64_t* rows, const int32_t* keys, int n) {
+    if (g->key_tiles_off || !g->key_tiles_valid) return;      // (invalid: rebuilt from device memory when next needed)
+    for (int i = 0; i < n; ++i) {
+        if (keys[i] < 0) continue;
+        const int32_t t = (int32_t)(rows[i] >> 8);
+        std::vector<int32_t>& v = g->key_tiles[keys[i]];
+        if (!v.empty() && v.back() == t) continue;
+        const auto it = std::lower_bound(v.begin(), v.end(), t);
+        if (it == v.end() || *it != t) {
+            v.insert(it, t);
+            if (++g->key_tiles_entries > g->key_tiles_limit()) { key_tiles_drop(g); return; }
+        }
+    }
+}
+
+// Rebuild from the keys in device memory (after a fill that generated them there).
+int key_tiles_rebuild(frhot_gallery* g) {
+    g->key_tiles.clear();
+    g->key_tiles_entries = 0;
+    if (g->nrows > 0) {
+        std::vector<int32_t> keys((size_t)g->nrows);
+        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+        HIP_TRY(hipMemcpy(keys.data(), g->keys, keys.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < g->nrows; ++r) {
+            if (keys[(size_t)r] < 0) continue;
+            std::vector<int32_t>& v = g->key_tiles[keys[(size_t)r]];
+            const int32_t t = (int32_t)(r >> 8);
+            if (v.empty() || v.back() != t) {                    // rows ascend, so do the tiles
+                v.push_back(t);
+                if (++g->key_tiles_entries > g->key_tiles_limit()) { key_tiles_drop(g); break; }
+            }
+        }
+    }
+    g->key_tiles_valid = true;
+    return FRHOT_OK;
+}
+
+int index_pin_grow(IndexPin& ip, size_t n) {
+    if (n <= ip.cap) return FRHOT_OK;
+    if (ip.p) { int32_t* old = ip.p; ip.p = nullptr; ip.cap = 0; HIP_TRY(hipHostFree(old)); }
+    const size_t cap = n + n / 2 + 1024;
+    HIP_TRY(hipHostMalloc((void**)&ip.p, cap * 4, hipHostMallocDefault));
+    ip.cap = cap;
+    return FRHOT_OK;
+}
+
+// Search with the queries' keys known on the host.  When it pays (or the gallery is told to), the
+// queries are brought into key order and every key's queries scan only the tiles that may hold
+// the key: one launch whose blocks each take one key's queries over a share of that key's tiles, and
+// one merge that writes the answers straight to the callers' order.
+// Otherwise the keys go to `qkeys_dev_buf` and one scan covers the whole gallery.  Same answers
+// either way: every row's key is still tested, and the listed tiles hold every row of the key.
+// `pin` must stay untouched until the stream has passed this call's copy (the caller's slot or
+// lock guarantees it).  Enqueues only; entered with ctx->mu held.
+int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys, int32_t* qkeys_dev_buf, int Bq, int k,
+                         float* scores_dev, int64_t* rows_dev, IndexPin& pin) {
+    frhot_ctx* c = g->ctx;
+    hipStream_t s = c->stream;
+    auto whole = [&]() -> int {
+        if (qkeys) HIP_TRY(hipMemcpyAsync(qkeys_dev_buf, qkeys, (size_t)Bq * 4, hipMemcpyHostToDevice, s));
+        return search_enqueue(g, q16, qkeys ? qkeys_dev_buf : nullptr, Bq, k, scores_dev, rows_dev, 0);
+    };
+    if (!qkeys || g->search_mode == FRHOT_SEARCH_WHOLE || g->key_tiles_off || g->nrows == 0 || Bq <= 0 || k <= 0 ||
+        k > 16 || !q16 || !scores_dev || !rows_dev)
+        return whole();                              // (argument errors are reported by search_enqueue)
+    if (!g->key_tiles_valid) {
+        const int rc = key_tiles_rebuild(g);
+        if (rc) return rc;
+        if (g->key_tiles_off) return whole();
+    }
+    // queries in key order (stable: equal keys keep the callers' order)
+    std::vector<int32_t> ord((size_t)Bq);
+    for (int i = 0; i < Bq; ++i) ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return qkeys[a] < qkeys[b]; });
+    struct Group { int qbeg, qn; const std::vector<int32_t>* tiles; size_t toff; bool any; };
+    std::vector<Group> groups;
+    static const std::vector<int32_t> none;
+    size_t ntl_total = 0;
+    for (int i = 0; i < Bq;) {
+        const int32_t key = qkeys[ord[(size_t)i]];
+        int j = i;
+        while (j < Bq && qkeys[ord[(size_t)j]] == key) ++j;
+        Group gr{i, j - i, &none, ntl_total, key == FRHOT_KEY_ANY};
+        if (!gr.any) {
+            const auto it = g->key_tiles.find(key);
+            if (it != g->key_tiles.end()) gr.tiles = &it->second;
+            ntl_total += gr.tiles->size();
+        }
+        groups.push_back(gr);
+        i = j;
+    }
+    // Work items: every key's queries in 64-query tiles, each tile's scan spread over nb walkers.
+    const int64_t all_tiles = (g->nrows + 255) / 256;
+    int qt_total = 0;
+    for (const Group& gr : groups)
+        if (gr.any || !gr.tiles->empty()) qt_total += (gr.qn + 63) / 64;
+    const int budget = qt_total > 0 ? std::max(1, std::min(256, 512 / qt_total)) : 1;
+    std::vector<ScanWork> work;
+    std::vector<int32_t> nlists((size_t)Bq, 0);        // per query (in key order): lists to merge
+    int max_nb = 1;
+    double bytes = 0.0, longest = 0.0;                 // for the cost rule: bytes read, longest walk in tiles
+    bool long_walks = false;
+    for (const Group& gr : groups) {
+        const int64_t ntl = gr.any ? all_tiles : (int64_t)gr.tiles->size();
+        if (ntl == 0) continue;
+        const int nb = (int)std::min<int64_t>(ntl, budget);
+        if (nb > max_nb) max_nb = nb;
+        if (ntl / nb >= 24) long_walks = true;
+        for (int i = 0; i < gr.qn; ++i) nlists[(size_t)(gr.qbeg + i)] = nb;
+        for (int q0 = gr.qbeg; q0 < gr.qbeg + gr.qn; q0 += 64)
+            for (int gb = 0; gb < nb; ++gb)
+                work.push_back(ScanWork{q0, gr.qbeg + gr.qn, gr.any ? -1 : (int32_t)gr.toff, (int32_t)ntl, gb, nb});
+        bytes += (double)((gr.qn + 63) / 64) * (double)ntl * 256.0 * g->D * 2.0;
+        longest = std::max(longest, std::ceil((double)ntl / nb));
+    }
+    if (g->search_mode == FRHOT_SEARCH_AUTO) {
+        // microseconds: a scan streams about 6.5 TB/s when it fills the chip and a lone block walks a
+        // tile in D/64 steps of about 0.45 us; the whole-gallery scan is bound by bytes (or, past 256
+        // queries, by the equal MFMA time of every further 256)
+        const double per_us = 6.5e6;
+        const double whole_us = 20.0 + (double)all_tiles * 256.0 * g->D * 2.0 * std::ceil(Bq / 256.0) / per_us;
+        const double by_key_us = 30.0 + std::max(bytes / per_us, longest * (g->D / 64) * 0.45);
+        if (work.size() > 65535 || by_key_us > 0.9 * whole_us) return whole();
+    }
+    if (work.empty()) return search_fill_empty(s, Bq, k, scores_dev, rows_dev);     // no key has a row
+    // index arrays: [order | keys in that order | lists per query | tile lists | work items]
+    const size_t o_keys = (size_t)Bq, o_nl = 2 * (size_t)Bq, o_tiles = 3 * (size_t)Bq, o_work = o_tiles + ntl_total;
+    const size_t nidx = o_work + work.size() * (sizeof(ScanWork) / 4);
+    int rc = index_pin_grow(pin, nidx);
+    if (rc) return rc;
+    if (nidx > g->idx_dev_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->idx_dev_cap = 0;
+        HIP_TRY(free_null(g->idx_dev));
+        const size_t cap = nidx + nidx / 2 + 1024;
+        HIP_TRY(hipMalloc((void**)&g->idx_dev, cap * 4));
+        g->idx_dev_cap = cap;
+    }
+    const size_t qbytes = (size_t)Bq * g->D * 2;
+    if (qbytes > g->q16s_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->q16s_cap = 0;
+        HIP_TRY(free_null(g->q16s));
+        const size_t cap = qbytes + qbytes / 2;
+        HIP_TRY(hipMalloc(&g->q16s, cap));
+        g->q16s_cap = cap;
+    }
+    const int kl = scan_list_len(k);
+    const size_t need = (size_t)max_nb * (size_t)Bq * (size_t)kl;
+    if (need > g->part_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->part_cap = 0;
+        HIP_TRY(free_null(g->part_s));
+        HIP_TRY(free_null(g->part_r));
+        HIP_TRY(hipMalloc((void**)&g->part_s, need * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&g->part_r, need * sizeof(int64_t)));
+        g->part_cap = need;
+    }
+    if (long_walks && scan_bound_bytes(Bq) > g->qbound_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        g->qbound_cap = 0;
+        HIP_TRY(free_null(g->qbound));
+        const size_t cap = scan_bound_bytes(Bq + Bq / 2);
+        HIP_TRY(hipMalloc((void**)&g->qbound, cap));
+        g->qbound_cap = cap;
+    }
+    int32_t* const h = pin.p;
+    for (int i = 0; i < Bq; ++i) {
+        h[i] = ord[(size_t)i];
+        h[o_keys + i] = qkeys[ord[(size_t)i]];
+        h[o_nl + i] = nlists[(size_t)i];
+    }
+    for (const Group& gr : groups)
+        if (!gr.tiles->empty()) memcpy(h + o_tiles + gr.toff, gr.tiles->data(), gr.tiles->size() * 4);
+    memcpy(h + o_work, work.data(), work.size() * sizeof(ScanWork));
+    HIP_TRY(hipMemcpyAsync(g->idx_dev, h, nidx * 4, hipMemcpyHostToDevice, s));
+    const int32_t* const ord_dev = g->idx_dev;
+    HIP_TRY(launch_rows_gather_f16(q16, ord_dev, Bq, g->D, g->q16s, s));
+    if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
+    HIP_TRY(launch_scan_topk_work(g->rows, g->keys, g->nrows, g->D, g->q16s, g->idx_dev + o_keys, Bq, k, g->part_s,
+                                  g->part_r, long_walks ? g->qbound : nullptr, g->idx_dev + o_tiles,
+                                  (const ScanWork*)(g->idx_dev + o_work), (int)work.size(), s));
+    if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
+    // every query merges its key's walkers' lists (none: the empty answer) and writes to its caller's row
+    HIP_TRY(launch_topk_final(g->part_s, g->part_r, max_nb, kl, Bq, k, 0, scores_dev, rows_dev, s, ord_dev,
+                              g->idx_dev + o_nl));
+    if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
+    return FRHOT_OK;
+}
+
 // Staging for n rows (and, with `with_rows`, n fp16 rows).  Buffers above kMutKeep rows are
 // released again by gallery_trim_mutation_staging after the call.
 constexpr size_t kMutKeep = 4096;
@@ -567,6 +789,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
         if (sl.dev) (void)hipFree(sl.dev);
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
+        if (sl.idx.p) (void)hipHostFree(sl.idx.p);
         if (sl.emb_pin) (void)hipHostFree(sl.emb_pin);
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -750,14 +973,26 @@ int frhot_gallery_destroy(frhot_gallery* g) {
     DeviceGuard dg(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     void* ptrs[] = {g->rows, g->keys, g->part_s, g->part_r, g->qbound, g->up_vecs, g->up_keys, g->up_rows,
-                    g->q16, g->q32, g->qk, g->out_s, g->out_r, g->mut_rows, g->mut_keys, g->mut_f16};
+                    g->q16, g->q32, g->qk, g->out_s, g->out_r, g->mut_rows, g->mut_keys, g->mut_f16, g->idx_dev, g->q16s};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (g->idx.p) (void)hipHostFree(g->idx.p);
     delete g;
     return FRHOT_OK;
     });
 }
 
 int64_t frhot_gallery_rows(frhot_gallery* g) { return g ? g->nrows : 0; }
+
+int frhot_gallery_search_mode(frhot_gallery* g, int mode) {
+    return guarded([&]() -> int {
+    if (!g) return fail(FRHOT_EINVAL, "gallery is null");
+    if (mode != FRHOT_SEARCH_AUTO && mode != FRHOT_SEARCH_BY_KEY && mode != FRHOT_SEARCH_WHOLE)
+        return fail(FRHOT_EINVAL, "search mode %d is not one of FRHOT_SEARCH_AUTO / _BY_KEY / _WHOLE", mode);
+    std::lock_guard<std::mutex> lk(g->ctx->mu);
+    g->search_mode = mode;
+    return FRHOT_OK;
+    });
+}
 
 int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* keys, const int64_t* rows, int n) {
     return guarded([&]() -> int {
@@ -798,6 +1033,7 @@ int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* key
     }
     if (!(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
     if (hi + 1 > g->nrows) g->nrows = hi + 1;
+    key_tiles_add(g, rows, keys, n);
     return FRHOT_OK;
     });
 }
@@ -827,7 +1063,7 @@ int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, 
     return guarded([&]() -> int {
     if (!g) return fail(FRHOT_EINVAL, "gallery is null");
     if (row0 < 0 || n <= 0 || row0 + n > g->capacity) return fail(FRHOT_ECAPACITY, "rows [%lld,%lld) outside capacity %lld", (long long)row0, (long long)(row0 + n), (long long)g->capacity);
-    if (nkeys < 0 || dup_every < 0 || dup_every == 1) return fail(FRHOT_EINVAL, "bad nkeys / dup_every");
+    if (dup_every < 0 || dup_every == 1) return fail(FRHOT_EINVAL, "bad dup_every");
     frhot_ctx* c = g->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard dg(c->device);
@@ -835,6 +1071,7 @@ int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (row0 > g->nrows) g->dense = false;
     if (row0 + n > g->nrows) g->nrows = row0 + n;
+    g->key_tiles_valid = false;         // the kernel derived the keys: a by-key search reads them back first
     return FRHOT_OK;
     });
 }
@@ -890,6 +1127,7 @@ int frhot_gallery_write_f16(frhot_gallery* g, const void* rows_f16, const int32_
     if (e != hipSuccess) return fail(FRHOT_EHIP, "gallery write failed: %s", hipGetErrorString(e));
     if (any_dead || !(inside || (contiguous && rows[0] <= g->nrows))) g->dense = false;
     if (hi + 1 > g->nrows) g->nrows = hi + 1;
+    key_tiles_add(g, rows, keys, n);
     return FRHOT_OK;
     });
 }
@@ -942,10 +1180,9 @@ int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq,
     if (rc) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(g->q32, q, (size_t)Bq * g->D * 4, hipMemcpyHostToDevice, s));
-    if (qkeys) HIP_TRY(hipMemcpyAsync(g->qk, qkeys, (size_t)Bq * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_f32_to_unit_f16(g->q32, g->q16, Bq, g->D, s));
-    rc = search_enqueue(g, g->q16, qkeys ? g->qk : nullptr, Bq, k, g->out_s, g->out_r, 0);
-    if (rc) return rc;
+    rc = search_keyed_enqueue(g, g->q16, qkeys, g->qk, Bq, k, g->out_s, g->out_r, g->idx);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
     HIP_TRY(hipMemcpyAsync(scores, g->out_s, (size_t)Bq * k * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(rows, g->out_r, (size_t)Bq * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -992,10 +1229,9 @@ int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops,
     int64_t* const pin_r = (int64_t*)(sl.res_pin + (size_t)c->max_batch * 16 * 4);
     rc = run_staged(c, sl, [&]() -> int {
         hipStream_t s = c->stream;
-        if (qkeys) HIP_TRY(hipMemcpyAsync(c->qkeys_dev, qkeys, (size_t)B * 4, hipMemcpyHostToDevice, s));
         int r = embed_enqueue(c, sl.dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D);
         if (r) return r;
-        r = search_enqueue(g, c->q_dev, qkeys ? c->qkeys_dev : nullptr, B, k, c->res_s, c->res_r, 0);
+        r = search_keyed_enqueue(g, c->q_dev, qkeys, c->qkeys_dev, B, k, c->res_s, c->res_r, sl.idx);
         if (r) return r;
         if (emb_out) HIP_TRY(hipMemcpyAsync(sl.emb_pin, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(pin_s, c->res_s, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));

@@ -66,6 +66,27 @@ void scan_set_bound_min_tiles(int tiles);   // blocks that walk fewer tiles scan
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
                             float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s);
+// The same over the `ntl` 256-row tiles listed in `tile_list` (device memory, tile numbers of the
+// whole gallery; row numbers in the answer stay those of the whole gallery) instead of all tiles.
+hipError_t launch_scan_topk_tiles(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
+                                  const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
+                                  float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s,
+                                  const int32_t* tile_list, int64_t ntl);
+// One block's share of a search that looks up every key's queries in that key's tiles only.
+struct ScanWork {
+    int32_t q0, qend;       // first query of the block's 64-query tile; end of its key's queries
+    int32_t tile_off, ntl;  // the key's tile list: offset into tile_lists (< 0: every tile of the gallery) and length
+    int32_t gb, nb;         // this block walks tiles gb, gb + nb, ... of the list
+};
+// One launch over `nwork` such items; the queries (device, [Bq, D] fp16) are in key order and
+// qkeys holds their keys in the same order.  Candidate lists land at
+// part[(gb * Bq + query) * list length]: part_s / part_r hold (largest nb) * Bq lists.
+hipError_t launch_scan_topk_work(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D, const void* q_f16,
+                                 const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r,
+                                 unsigned* qbound, const int32_t* tile_lists, const ScanWork* work, int nwork,
+                                 hipStream_t s);
+// out[i] = in[index[i]]: n rows of D fp16 (D a multiple of 8), all device memory.
+hipError_t launch_rows_gather_f16(const void* in, const int32_t* index, int n, int D, void* out, hipStream_t s);
 // Upper bound on the list entries (one score and one row each) launch_scan_topk writes to
 // part_s / part_r for Bq queries of top-k, whatever the gallery size.
 size_t scan_part_entries(int Bq, int k);
@@ -81,7 +102,9 @@ hipError_t scan_static_scratch(int device, ScanStaticScratch* out);
 int scan_list_len(int k);
 // Final selection over nlists lists of kin (layout [nlists][Bq][kin]) -> best kout per query.
 hipError_t launch_topk_final(const float* cand_s, const int64_t* cand_r, int nlists, int kin, int Bq, int kout,
-                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s);
+                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s,
+                             const int32_t* out_index = nullptr,      // query i's answer goes to row out_index[i]
+                             const int32_t* nlists_q = nullptr);      // query i merges its first nlists_q[i] lists
 
 // Sets the dynamic-LDS attributes and resolves the static scratch's address on the CURRENT device;
 // call once per device (repeat calls are cheap).

@@ -532,7 +532,11 @@ __global__ __launch_bounds__(256) void gallery_fill_kernel(half_t* __restrict__ 
     const float inv = ss == 0 ? 1.0f : __fdiv_rn(1.0f, nrm);
     for (int c = lane; c < D; c += 64)
         g[gal_index(r, c, D >> 6)] = (half_t)__fmul_rn((float)synth_value(seed, src, D, c), inv);
-    if (lane == 0) gk[r] = nkeys > 0 ? (int32_t)(splitmix64(seed ^ (src * 0xD1B54A32D192ED03ull)) % (uint64_t)nkeys) : 0;
+    // keys: hashed over nkeys values, or (nkeys < 0) runs of -nkeys consecutive rows per key
+    if (lane == 0)
+        gk[r] = nkeys > 0   ? (int32_t)(splitmix64(seed ^ (src * 0xD1B54A32D192ED03ull)) % (uint64_t)nkeys)
+                : nkeys < 0 ? (int32_t)(src / (uint64_t)(-(int64_t)nkeys))
+                            : 0;
 }
 
 __global__ __launch_bounds__(256) void gallery_gather_kernel(const half_t* __restrict__ g,
@@ -556,6 +560,16 @@ __global__ __launch_bounds__(256) void gallery_scatter_kernel(const half_t* __re
     const int64_t r = rows[i];
     for (int c = lane * 8; c < D; c += 512) *(half8*)(g + gal_index(r, c, D >> 6)) = *(const half8*)(in + (size_t)i * D + c);
     if (lane == 0) gk[r] = in_keys[i];
+}
+
+// out[i] = in[index[i]] for n rows of D halfs (queries brought into key order).
+__global__ __launch_bounds__(256) void rows_gather_f16_kernel(const half_t* __restrict__ in,
+                                                              const int32_t* __restrict__ index, int n, int D,
+                                                              half_t* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const size_t src = (size_t)index[i] * D, dst = (size_t)i * D;
+    for (int c = lane * 8; c < D; c += 512) *(half8*)(out + dst + c) = *(const half8*)(in + src + c);
 }
 
 __global__ __launch_bounds__(256) void f32_to_unit_f16_kernel(const float* __restrict__ q, half_t* __restrict__ o,
@@ -1399,7 +1413,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                                                            const half_t* __restrict__ q,
                                                            const int32_t* __restrict__ qkeys, int Bq, int nb,
                                                            float* __restrict__ part_s, long long* __restrict__ part_r,
-                                                           unsigned* __restrict__ qbound) {
+                                                           unsigned* __restrict__ qbound,
+                                                           const int32_t* __restrict__ tile_list, long ntl,
+                                                           const ScanWork* __restrict__ work) {
     static_assert(WX * WY == 8 && RY % 64 == 0, "shape");
     constexpr int TX = 256 / WX, TY = RY / WY, NX = TX / 16, NY = TY / 16;
     constexpr int XB = 256 * 128, YB = RY * 128;
@@ -1426,12 +1442,25 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     unsigned long long sc_tc = 0, sc_td = 0, sc_pre = 0, sc_prel = 0, sc_loop = 0;
     FR_STAMP(sc_t0);
 #endif
-    const int qtiles = gridDim.x / nb;
-    const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
-    const int qt = seq % qtiles, gb = (seq / qtiles) * 8 + xcd;
-    const int q0 = qt * RY;
+    // Either a regular grid (nb walkers for each of gridDim.x / nb query tiles, all over the same
+    // tiles), or one ScanWork item per block: the query tile, the tile list and the walker number
+    // of a search that looks up every key's queries in that key's tiles only.
+    int qtiles, q0, gb, bql = Bq;       // bql: queries at and past this one are not this block's
+    if (work) {
+        const ScanWork w = work[blockIdx.x];
+        q0 = w.q0; bql = w.qend; gb = w.gb; nb = w.nb; ntl = w.ntl;
+        tile_list = w.tile_off >= 0 ? tile_list + w.tile_off : nullptr;
+        qtiles = 2;                     // other blocks may read the same tiles: keep them in L2
+    } else {
+        qtiles = gridDim.x / nb;
+        const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
+        gb = (seq / qtiles) * 8 + xcd;
+        q0 = (seq % qtiles) * RY;
+    }
     const int nk = D / 64;
-    const long ntiles = (nrows + 255) / 256;
+    // With a tile list the launch scans only the listed 256-row tiles (the tiles that may hold rows
+    // of the queries' key), in list order; row numbers stay those of the whole gallery.
+    const long ntiles = tile_list ? ntl : (nrows + 255) / 256;
     const long my_tiles = gb < ntiles ? (ntiles - gb + nb - 1) / nb : 0;
     const long S = my_tiles * nk;
     const int cb = ((l7 ^ (lane >> 3)) << 4);
@@ -1446,7 +1475,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     // the query block's offsets are the gallery tile's plus the query tile's first row (a uniform
     // term): they are rebuilt from xo0 at every use instead of occupying a register of their own
     const unsigned yq0 = (unsigned)q0 * (unsigned)D * 2u;
-    const unsigned yomax = (unsigned)(Bq - 1) * (unsigned)D * 2u + (unsigned)cb;
+    const unsigned yomax = (unsigned)(bql - 1) * (unsigned)D * 2u + (unsigned)cb;
     const unsigned pstride = 64u * (unsigned)D * 2u;
     TopK<K> top[NY];
 #pragma unroll
@@ -1462,7 +1491,8 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         long itile = gb; int iks = 0;   // next gallery step to issue
         int yks = 0;                    // next query slice to issue
         auto issue_x = [&](int slot) __attribute__((always_inline)) {
-            const char* const base = (const char*)gal + ((size_t)itile * nk + (size_t)iks) * 32768;
+            const long ptile = tile_list ? (long)tile_list[itile] : itile;
+            const char* const base = (const char*)gal + ((size_t)ptile * nk + (size_t)iks) * 32768;
 #pragma unroll
             // with one query tile every gallery byte is read by one CU, once: stream it non-temporally
             // (+3..6 % on the HBM-bound shapes); with several, the other tiles' blocks want it in L2
@@ -1570,7 +1600,8 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #if FR_DBG & 64
                 FR_STAMP(sc_ta);
 #endif
-                const int rbase = (int)(tile * 256) + wx * TX + g0 * 4;     // rows fit 31 bits (checked at launch)
+                const long ptile = tile_list ? (long)tile_list[tile] : tile;
+                const int rbase = (int)(ptile * 256) + wx * TX + g0 * 4;    // rows fit 31 bits (checked at launch)
                 // Rows whose key does not match the query's, and rows past the end of the gallery (last
                 // tile only), are struck out of the accumulators in place (the next tile starts
                 // from zero anyway): the selection then reads the accumulators themselves and needs no copy.
@@ -1602,7 +1633,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #pragma unroll
                     for (int y = 0; y < NY; ++y) {
                         const int qq = q0 + wy * TY + y * 16 + l15;
-                        mykey[y] = (qkeys && qq < Bq) ? qkeys[qq] : -2;
+                        mykey[y] = (qkeys && qq < bql) ? qkeys[qq] : -2;
                     }
 #pragma unroll
                     for (int y = 0; y < NY; ++y) {
@@ -1619,7 +1650,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         }
                     }
                 }
-                if ((tile + 1) * 256 > nrows) {
+                if ((ptile + 1) * 256 > nrows) {
                     const int nr = (int)nrows;
 #pragma unroll
                     for (int y = 0; y < NY; ++y)
@@ -1891,7 +1922,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         unsigned hk = r >= 0 ? ordered_key(hs[0]) : 0u;
         unsigned hr = r >= 0 ? (unsigned)r : 0xffffffffu;
         const size_t o = ((size_t)gb * Bq + q0 + ql) * K;
-        const bool writer = sub == 0 && q0 + ql < Bq;
+        const bool writer = sub == 0 && q0 + ql < bql;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const unsigned kmax = group_umax<NL>(hk);
@@ -1944,8 +1975,11 @@ template <int K>
 __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict__ cs,
                                                         const long long* __restrict__ cr, int nlists, int kin,
                                                         int Bq, int kout, long long row_base,
-                                                        float* __restrict__ out_s, long long* __restrict__ out_r) {
+                                                        float* __restrict__ out_s, long long* __restrict__ out_r,
+                                                        const int32_t* __restrict__ out_index,
+                                                        const int32_t* __restrict__ nlists_q) {
     constexpr int NL = 4;                         // lists per lane: nlists <= 256 (checked at launch)
+    if (nlists_q) nlists = nlists_q[blockIdx.x];  // this query's own number of lists (may be 0)
     __shared__ float ls[K * 64 * NL];
     __shared__ long long lr[K * 64 * NL];
     const int qi = blockIdx.x, lane = threadIdx.x;
@@ -1987,8 +2021,10 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
         const long long rwin = (long long)(((unsigned long long)hmin << 32) | lmin);
         const bool found = kmax != 0u;
         if (lane == 0) {
-            out_s[(size_t)qi * kout + o] = found ? ordered_value(kmax) : -INFINITY;
-            out_r[(size_t)qi * kout + o] = found ? rwin + row_base : -1;
+            // `out_index` (or the query number itself) is the answer row this query's result goes to
+            const size_t qo = out_index ? (size_t)out_index[qi] : (size_t)qi;
+            out_s[qo * kout + o] = found ? ordered_value(kmax) : -INFINITY;
+            out_r[qo * kout + o] = found ? rwin + row_base : -1;
         }
         if (!found) continue;                                    // uniform: every list is exhausted
         // one lane advances the list that supplied the winner (the lowest lane, should two hold it)
@@ -2280,7 +2316,8 @@ hipError_t scan_static_scratch(int device, ScanStaticScratch* out) {
 template <int K, int RY, int WX, int WY, bool USE_KEYS>
 static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
                             int Bq, int nb, float* part_s, int64_t* part_r, unsigned* qbound, hipStream_t s,
-                            bool attr_only) {
+                            bool attr_only, const int32_t* tile_list = nullptr, long ntl = 0,
+                            const ScanWork* work = nullptr, int nwork = 0) {
     constexpr int xs = RY <= 64 ? 4 : 3, ys = RY <= 128 ? 3 : 2;
     constexpr int bounds = RY <= 64 ? RY * ((K + 3) & ~3) * 4 : 0;        // block-level score bounds
     constexpr int ring = xs * 256 * 128 + ys * RY * 128 + bounds;
@@ -2290,19 +2327,20 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS>;
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk, nrows, D,
-                       (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r, qbound);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(work ? nwork : nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk,
+                       nrows, D, (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r, qbound, tile_list, ntl,
+                       work);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
 
 static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const int32_t* gk, long nrows, int D,
                                 const void* q, const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr,
-                                unsigned* qb, hipStream_t s, bool attr) {
+                                unsigned* qb, hipStream_t s, bool attr, const int32_t* tl = nullptr, long ntl = 0) {
 #define FR_SCAN(K, RY, WX, WY)                                                                              \
     if (kl == K && ry == RY)                                                                                  \
-        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr)  \
-                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr);
+        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr, tl, ntl)  \
+                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr, tl, ntl);
     FR_SCAN(5, 64, 4, 2)
     FR_SCAN(5, 128, 4, 2)
     FR_SCAN(5, 256, 2, 4)
@@ -2325,15 +2363,25 @@ size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 1
 hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
                             const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
                             unsigned* qbound, int* nblk_out, hipStream_t s) {
+    return launch_scan_topk_tiles(g, gk, nrows, D, q, qkeys, use_keys, Bq, k, part_s, part_r, qbound, nblk_out, s,
+                                  nullptr, 0);
+}
+
+// The same over the `ntl` tiles listed in `tile_list` (device; 256-row tile numbers, each below
+// the gallery's tile count) instead of all of them; a null list scans the whole gallery.
+hipError_t launch_scan_topk_tiles(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
+                                  const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
+                                  unsigned* qbound, int* nblk_out, hipStream_t s, const int32_t* tile_list,
+                                  int64_t ntl) {
     if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q ||
-        !part_s || !part_r || !nblk_out || (use_keys && !gk))
+        !part_s || !part_r || !nblk_out || (use_keys && !gk) || (tile_list && ntl <= 0))
         return hipErrorInvalidValue;
     // the kernel addresses the query block and a gallery tile with 32-bit lane offsets
     if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
     const int kl = scan_klist(k);
     const int ry = scan_query_tile(Bq, kl);
     const int qtiles = (Bq + ry - 1) / ry;
-    const long ntiles = (nrows + 255) / 256;
+    const long ntiles = tile_list ? (long)ntl : (long)((nrows + 255) / 256);
     int nb = scan_walkers(qtiles);
     const long nt8 = (ntiles + 7) & ~7L;
     if (nb > nt8) nb = (int)nt8;
@@ -2348,24 +2396,61 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
         if (e != hipSuccess) return e;
     }
     return scan_dispatch(kl, ry, use_keys != 0, g, gk, (long)nrows, D, q, qkeys, Bq, nb, part_s, part_r, qbound, s,
-                         false);
+                         false, tile_list, (long)ntl);
+}
+
+// One launch over a list of work items (device memory): block b scans, for the 64-query tile that
+// starts at work[b].q0 of the Bq queries, tiles gb, gb + nb, ... of its tile list.  The queries'
+// keys are tested on every row.  Candidate lists land at part[(gb * Bq + query) * scan_klist(k)],
+// so part_s / part_r hold (largest nb) * Bq lists; `qbound` as for launch_scan_topk, or null.
+hipError_t launch_scan_topk_work(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
+                                 const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r,
+                                 unsigned* qbound, const int32_t* tile_lists, const ScanWork* work, int nwork,
+                                 hipStream_t s) {
+    if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !gk || !q ||
+        !qkeys || !part_s || !part_r || !work || nwork <= 0)
+        return hipErrorInvalidValue;
+    if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
+    const int kl = scan_klist(k);
+    if (qbound) {
+        hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq), s);
+        if (e != hipSuccess) return e;
+    }
+#define FR_SCANW(K)                                                                                           \
+    if (kl == K)                                                                                              \
+        return scan_inst<K, 64, 4, 2, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r, qbound, s, false, \
+                                            tile_lists, 0, work, nwork);
+    FR_SCANW(5)
+    FR_SCANW(10)
+    FR_SCANW(16)
+#undef FR_SCANW
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rows_gather_f16(const void* in, const int32_t* index, int n, int D, void* out, hipStream_t s) {
+    if (n <= 0 || D <= 0 || D % 8 || !in || !index || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_gather_f16_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, (const half_t*)in, index,
+                       n, D, (half_t*)out);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
 }
 
 hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
-                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s) {
+                             int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s, const int32_t* out_index,
+                             const int32_t* nlists_q) {
     if (nlists <= 0 || nlists > 256 || kin <= 0 || kin > 16 || Bq <= 0 || kout <= 0 || kout > kin || !cs || !cr ||
         !out_s || !out_r)
         return hipErrorInvalidValue;
     const int kl = scan_klist(kin);
     if (kl == 5)
         hipLaunchKernelGGL((topk_final_kernel<5>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin, Bq,
-                           kout, (long long)row_base, out_s, (long long*)out_r);
+                           kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
     else if (kl == 10)
         hipLaunchKernelGGL((topk_final_kernel<10>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
-                           Bq, kout, (long long)row_base, out_s, (long long*)out_r);
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
     else
         hipLaunchKernelGGL((topk_final_kernel<16>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
-                           Bq, kout, (long long)row_base, out_s, (long long*)out_r);
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

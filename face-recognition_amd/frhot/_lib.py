@@ -42,6 +42,7 @@ SIGNATURES = {
     "frhot_gallery_read": (C.c_int, [_p, _i64p, C.c_int, _p, _i32p]),
     "frhot_gallery_write_f16": (C.c_int, [_p, _p, _i32p, _i64p, C.c_int]),
     "frhot_gallery_rows": (C.c_int64, [_p]),
+    "frhot_gallery_search_mode": (C.c_int, [_p, C.c_int]),
     "frhot_search": (C.c_int, [_p, _f32p, _i32p, C.c_int, C.c_int, _f32p, _i64p]),
     "frhot_search_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_search_dev_static": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),

@@ -194,6 +194,15 @@ class Gallery:
         check(self._lib.frhot_gallery_upsert(self._h, _ptr(vecs, C.c_float), _ptr(keys, C.c_int32),
                                              _ptr(rows, C.c_int64), n))
 
+    SEARCH_AUTO, SEARCH_BY_KEY, SEARCH_WHOLE = 0, 1, 2
+
+    def search_mode(self, mode: int):
+        """How searches whose queries carry keys look for rows: by key (only the 256-row tiles that
+        may hold a key are scanned: the reference searches one collection's
+        own storage, qdrant_database_FE/app.py:316-337), over the whole gallery, or whichever a cost
+        estimate prefers (the default).  The answers are the same."""
+        check(self._lib.frhot_gallery_search_mode(self._h, int(mode)))
+
     def tombstone(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
         check(self._lib.frhot_gallery_tombstone(self._h, _ptr(rows, C.c_int64), rows.size))

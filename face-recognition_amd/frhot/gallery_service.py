@@ -30,6 +30,47 @@ DIM = 4096
 SEARCH_LIMIT = 5
 
 
+TILE = 256      # rows per gallery tile: what one scan step covers and a by-key search skips or reads
+
+
+class _RowAllocator:
+    """Gallery rows handed out so that a key's rows sit together.  The reference keeps every
+    collection in storage of its own (qdrant_database_FE/app.py:108-128); here a key (collection,
+    store) takes whole 256-row tiles while unclaimed tiles last, so a search for that key reads only
+    its own tiles.  When every tile is claimed, rows are borrowed from the key with the most free
+    rows: still correct (the library lists every tile a key was written to), only less compact."""
+
+    def __init__(self, capacity: int):
+        self.capacity = int(capacity)
+        self._ntiles = (self.capacity + TILE - 1) // TILE
+        self._next_tile = 0
+        self._owner: dict[int, int] = {}            # tile -> key that claimed it
+        self._free: dict[int, list[int]] = {}       # key -> free rows in its tiles (taken from the end)
+
+    def free_count(self) -> int:
+        unclaimed = max(0, min(self.capacity, self._ntiles * TILE) - self._next_tile * TILE)
+        return unclaimed + sum(len(v) for v in self._free.values())
+
+    def alloc(self, key: int) -> int:
+        mine = self._free.get(key)
+        if mine:
+            return mine.pop()
+        if self._next_tile < self._ntiles:
+            t = self._next_tile
+            self._next_tile += 1
+            self._owner[t] = key
+            lo, hi = t * TILE, min((t + 1) * TILE, self.capacity)
+            self._free[key] = list(range(hi - 1, lo - 1, -1))      # ascending rows come off the end
+            return self._free[key].pop()
+        donor = max(self._free.items(), key=lambda kv: len(kv[1]), default=(None, None))[1]
+        if not donor:
+            raise MemoryError("gallery capacity exhausted")
+        return donor.pop(0)                                        # the donor's highest row
+
+    def release(self, row: int):
+        self._free.setdefault(self._owner[row // TILE], []).append(row)
+
+
 class GalleryService:
     def __init__(self, ctx, capacity: int = 1 << 16, dim: int = DIM, gallery=None):
         """`gallery`: an object with the upsert / tombstone / search / close methods of
@@ -45,8 +86,7 @@ class GalleryService:
         self._keys: dict[tuple, int] = {}          # (collection, store_id) -> device key
         self._points: dict[int, dict] = {}         # row -> {"uid", "payload", "collection", "seq"}
         self._by_id: dict[tuple, list] = {}        # (collection, payload id) -> rows in insertion order
-        self._free: list[int] = []
-        self._next_row = 0
+        self._rows = _RowAllocator(capacity)
         self._seq = 0
 
     def close(self):
@@ -83,14 +123,8 @@ class GalleryService:
             self._keys[k] = len(self._keys)
         return self._keys[k]
 
-    def _alloc_row(self) -> int:
-        if self._free:
-            return self._free.pop()
-        if self._next_row >= self.capacity:
-            raise MemoryError("gallery capacity exhausted")
-        r = self._next_row
-        self._next_row += 1
-        return r
+    def _alloc_row(self, key: int) -> int:
+        return self._rows.alloc(key)
 
     def _drop_rows(self, rows):
         if not rows:
@@ -102,7 +136,7 @@ class GalleryService:
             lst.remove(r)
             if not lst:
                 del self._by_id[(p["collection"], p["payload"]["id"])]
-            self._free.append(r)
+            self._rows.release(r)
 
     def _enforce_face_limit(self, collection, pid, limit=10):
         """app.py:207-240: among the first limit+5 points of this id, delete the oldest so limit-1 stay."""
@@ -143,11 +177,12 @@ class GalleryService:
                     old = self._points[row]
                     self.gallery.upsert(vec, self._key(collection_name, old["payload"].get("store_id")), [row])
                     return 201, {"message": "Point inserted"}
-                row = self._alloc_row()
+                key = self._key(collection_name, store_id)
+                row = self._alloc_row(key)
                 try:
-                    self.gallery.upsert(vec, self._key(collection_name, store_id), [row])
+                    self.gallery.upsert(vec, key, [row])
                 except Exception:
-                    self._free.append(row)          # the row was never written: hand it back
+                    self._rows.release(row)         # the row was never written: hand it back
                     raise
                 self._seq += 1
                 self._points[row] = {"uid": str(uuid.uuid4()), "payload": payload, "collection": collection_name,
@@ -312,7 +347,7 @@ class GalleryService:
                 # points dropped only after that succeeded: a snapshot that does not fit, or a
                 # failing device write, leaves the live collection as it was and leaks no row.
                 old_rows = [r for r, p in self._points.items() if p["collection"] == collection_name]
-                room = len(self._free) + (self.capacity - self._next_row)
+                room = self._rows.free_count()
                 if len(points) > room + len(old_rows):
                     return 404, {"message": f"snapshot holds {len(points)} points, the gallery has room for "
                                             f"{room + len(old_rows)}"}
@@ -325,12 +360,13 @@ class GalleryService:
                 rows, keys = [], []
                 try:
                     for pt in points:
-                        rows.append(self._alloc_row())
                         keys.append(self._key(collection_name, pt["payload"].get("store_id")))
+                        rows.append(self._alloc_row(keys[-1]))
                     if rows:
                         self.gallery.write_f16(vec, np.asarray(keys, np.int32), np.asarray(rows, np.int64))
                 except Exception:
-                    self._free.extend(rows)
+                    for r in rows:
+                        self._rows.release(r)
                     if rows:
                         try:        # whatever part of the write landed must not answer searches
                             self.gallery.tombstone(np.asarray(rows, dtype=np.int64))

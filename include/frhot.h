@@ -132,14 +132,35 @@ int frhot_gallery_destroy(frhot_gallery* g);
 int frhot_gallery_upsert(frhot_gallery* g, const float* vecs, const int32_t* keys,
                          const int64_t* rows, int n);
 
+/*
+ * How frhot_search / frhot_recognise (the calls that know their queries' keys on the host) look
+ * for rows.  The reference keeps every collection in storage of its own and a search reads that
+ * collection alone (qdrant_database_FE/app.py:108-128,316-337).  The gallery is one table, so the
+ * library keeps, per key, the list of 256-row tiles that may hold rows of the key, and a by-key
+ * search scans only those (one launch: every block takes one key's queries and a share of that
+ * key's tiles).  The answers are the same either way (every row's key is still tested).
+ *   FRHOT_SEARCH_AUTO    by key when a cost estimate says it is the faster way (default)
+ *   FRHOT_SEARCH_BY_KEY  by key whenever the queries carry keys
+ *   FRHOT_SEARCH_WHOLE   always one scan of the whole gallery
+ * Rows of a key that sit together (the host side allocates a key's rows from tiles of its own
+ * while it can) make the lists short; a gallery whose keys are strewn over every tile (more than
+ * 8 list entries per tile on average) gives the lists up and scans whole, whatever the mode.  The *_dev searches, whose keys live on the device, always
+ * scan the whole gallery.
+ */
+#define FRHOT_SEARCH_AUTO    0
+#define FRHOT_SEARCH_BY_KEY  1
+#define FRHOT_SEARCH_WHOLE   2
+int frhot_gallery_search_mode(frhot_gallery* g, int mode);
+
 /* Mark rows deleted (key := FRHOT_KEY_DEAD).  Replaces: client.delete of
  * qdrant_database_FE/app.py:237-240,423-435. */
 int frhot_gallery_tombstone(frhot_gallery* g, const int64_t* rows, int n);
 
 /*
  * Fill rows [row0, row0+n) with the library's deterministic synthetic gallery
- * (integer hash -> unit fp16 rows; `nkeys` > 0 assigns key = hash % nkeys, else
- * key 0) and plant every `dup_every`-th row as an exact duplicate of its
+ * (integer hash -> unit fp16 rows; `nkeys` > 0 assigns key = hash % nkeys, `nkeys`
+ * < 0 key = row / -nkeys, i.e. runs of -nkeys rows per key as collections stored
+ * one after the other, 0 key 0) and plant every `dup_every`-th row as an exact duplicate of its
  * predecessor (0: none).  Benchmark / test data only; no reference counterpart.
  */
 int frhot_gallery_fill_synthetic(frhot_gallery* g, uint64_t seed, int64_t row0, int64_t n,

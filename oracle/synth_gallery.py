@@ -47,7 +47,9 @@ def rows_f16(seed: int, rows, d: int, dup_every: int = 0) -> np.ndarray:
 
 def keys(seed: int, rows, nkeys: int, dup_every: int = 0) -> np.ndarray:
     src = source_rows(rows, dup_every).astype(np.uint64)
-    if nkeys <= 0:
+    if nkeys < 0:                      # runs of -nkeys consecutive rows per key
+        return (src // np.uint64(-nkeys)).astype(np.int32)
+    if nkeys == 0:
         return np.zeros(len(src), dtype=np.int32)
     with np.errstate(over="ignore"):
         h = splitmix64(np.uint64(seed) ^ (src * np.uint64(0xD1B54A32D192ED03)))

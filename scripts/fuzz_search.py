@@ -61,6 +61,7 @@ def one_case(ctx, rng, case):
             gal.tombstone(dead)
             keys = keys.copy()
             keys[dead] = -1
+        gal.search_mode(int(rng.integers(0, 3)))      # cost rule / by key / whole gallery: the same answer
         got_s, got_r = gal.search(q, qkeys, k)
         ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys, qkeys=qkeys, gallery_dtype=np.float16)
         qn = osr.unit_rows(q).astype(np.float16).astype(np.float32)

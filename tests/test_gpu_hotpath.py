@@ -324,6 +324,123 @@ def test_search_key_filter_and_tombstones(gpu_ctx):
     gal.close()
 
 
+def test_search_by_key_equals_whole_scan(gpu_ctx):
+    """A search whose queries carry keys may scan only the tiles that can hold each key (the reference
+    searches one collection's own storage, qdrant_database_FE/app.py:316-337).  Whatever the way,
+    the answer is the same, bit for bit: keys clustered in tiles of their own, keys scattered over
+    every tile, a key spread one row per tile, rows that died or moved to another key, a key nobody
+    has, ANY queries; also against the oracle, and after a fill whose keys were derived on the
+    device (the tile lists are then rebuilt from device memory)."""
+    from frhot import synth
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    n, d, k = 20_000, 128, 5
+    rng = np.random.default_rng(2026)
+    g = synth.unit_gallery(seed=91, n=n, d=d)
+    keys = np.empty(n, np.int32)
+    keys[:] = 100 + rng.integers(0, 5, size=n)                   # scattered: five keys over every tile
+    for j in range(12):                                          # clustered: key j in rows 768 j .. of its own
+        lo = 768 * j
+        keys[lo:lo + 500 + 20 * j] = j
+    keys[np.arange(30, n, 256)] = 50                             # one row in every tile
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, keys, np.arange(n))
+    dead = rng.choice(n, size=300, replace=False)
+    gal.tombstone(dead)
+    keys_ref = keys.copy()
+    keys_ref[dead] = -1
+    moved = np.setdiff1d(np.arange(0, 400), dead)[:50]           # rows of key 0 re-written under key 7
+    gal.upsert(g[moved], np.full(moved.size, 7, np.int32), moved)
+    keys_ref[moved] = 7
+    bq = 300
+    targets = rng.integers(0, n, size=bq)
+    q = synth.planted_queries(rng, g[targets], 0.8)
+    qkeys = np.where(keys_ref[targets] >= 0, keys_ref[targets], 3).astype(np.int32)
+    qkeys[:20] = -2
+    qkeys[20:25] = 999                                           # nobody has it
+    qkeys[25:40] = 50
+    qkeys[40:60] = 7
+    out = {}
+    for mode in (Gallery.SEARCH_WHOLE, Gallery.SEARCH_BY_KEY, Gallery.SEARCH_AUTO):
+        gal.search_mode(mode)
+        out[mode] = gal.search(q, qkeys, k)
+    for mode in (Gallery.SEARCH_BY_KEY, Gallery.SEARCH_AUTO):
+        assert np.array_equal(out[mode][1], out[Gallery.SEARCH_WHOLE][1])
+        assert np.array_equal(out[mode][0], out[Gallery.SEARCH_WHOLE][0])
+    got_s, got_r = out[Gallery.SEARCH_BY_KEY]
+    ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys_ref, qkeys=qkeys, gallery_dtype=np.float16)
+    full = osr.unit_rows(q).astype(np.float16).astype(np.float32) @ osr.unit_rows(g).astype(np.float16).astype(np.float32).T
+    _check_topk(got_s, got_r, ref_s, ref_r, full, tol=2e-5)
+    assert (got_r[20:25] == -1).all() and np.isneginf(got_s[20:25]).all()
+    # one query, one key: the serving shape
+    gal.search_mode(Gallery.SEARCH_BY_KEY)
+    s1, r1 = gal.search(q[100:101], qkeys[100:101], k)
+    assert np.array_equal(r1[0], got_r[100]) and np.array_equal(s1[0], got_s[100])
+    gal.close()
+    # keys derived on the device
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=5, row0=0, n=n, nkeys=40, dup_every=0)
+    rows16, rkeys = gal.read(targets)
+    qk = rkeys.astype(np.int32)
+    gal.search_mode(Gallery.SEARCH_WHOLE)
+    sw, rw = gal.search(rows16.astype(np.float32), qk, k)
+    gal.search_mode(Gallery.SEARCH_BY_KEY)
+    sb, rb = gal.search(rows16.astype(np.float32), qk, k)
+    assert np.array_equal(rw, rb) and np.array_equal(sw, sb)
+    assert (sb[:, 0] >= 0.999).all()
+    gal.close()
+    # keys strewn over every tile (100 keys x 1172 tiles): the lists are given up, the answers stay right
+    n2 = 300_000
+    gal = Gallery(gpu_ctx, 64, n2)
+    gal.fill_synthetic(seed=6, row0=0, n=n2, nkeys=100, dup_every=0)
+    t2 = rng.integers(0, n2, size=40)
+    rows16, rkeys = gal.read(t2)
+    gal.search_mode(Gallery.SEARCH_BY_KEY)
+    sb, rb = gal.search(rows16.astype(np.float32), rkeys.astype(np.int32), k)
+    gal.search_mode(Gallery.SEARCH_WHOLE)
+    sw, rw = gal.search(rows16.astype(np.float32), rkeys.astype(np.int32), k)
+    assert np.array_equal(rw, rb) and np.array_equal(sw, sb) and (sb[:, 0] >= 0.999).all()
+    gal.close()
+
+
+def test_recognise_by_key_equals_whole_scan(gpu_ctx):
+    """The fused call (crops in, answers out) with keys: by key and over the whole gallery give the
+    same rows and scores, from two threads at once as well (each call's index arrays travel in its
+    own staging slot)."""
+    import threading
+    from frhot import synth
+    from frhot.engine import Gallery
+    imgs = synth.crops(seed=41, n=12, lo=120, hi=220)
+    emb = gpu_ctx.embed(imgs)
+    n = 6000
+    g = synth.unit_gallery(seed=42, n=n, d=4096, sparse=True)
+    keys = (np.arange(n) // 700).astype(np.int32)                # keys 0..8 in runs of 700 rows
+    for i in range(12):
+        g[500 * i + 7] = emb[i]
+    gal = Gallery(gpu_ctx, 4096, n)
+    gal.upsert(g, keys, np.arange(n))
+    qkeys = keys[[500 * i + 7 for i in range(12)]].copy()
+    qkeys[3] = -2
+    qkeys[5] = (qkeys[5] + 1) % 9                                # the wrong collection
+    gal.search_mode(Gallery.SEARCH_WHOLE)
+    sw, rw, _ = gpu_ctx.recognise(gal, imgs, qkeys, 5)
+    gal.search_mode(Gallery.SEARCH_BY_KEY)
+    sb, rb, _ = gpu_ctx.recognise(gal, imgs, qkeys, 5)
+    assert np.array_equal(rw, rb) and np.array_equal(sw, sb)
+    assert all(rb[i, 0] == 500 * i + 7 for i in range(12) if i != 5) and 500 * 5 + 7 not in rb[5]
+    res = [None, None]
+
+    def call(j):
+        res[j] = gpu_ctx.recognise(gal, imgs[::-1] if j else imgs, qkeys[::-1].copy() if j else qkeys, 5)
+    th = [threading.Thread(target=call, args=(j,)) for j in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(res[0][1], rb) and np.array_equal(res[1][1], rb[::-1])
+    gal.close()
+
+
 def test_dead_key_as_query_key_matches_nothing(gpu_ctx):
     """A query key of -1 (the tombstone value) or any other negative key but ANY is no row key:
     the host forms refuse it, the device-pointer form answers with no row at all, so deleted

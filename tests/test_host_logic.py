@@ -96,11 +96,11 @@ def test_gallery_service_validation_and_eviction_order():
     assert svc.search_point("", v, "S")[0] == 404
     assert svc.search_point("S_Employees", v, "ELSEWHERE") == (200, {"message": "Point not found", "data": []})
     assert svc.delete_point("S_Employees", "A") == (200, {"message": "Point deleted"})
-    assert svc.point_count("S_Employees") == 0 and len(svc._free) == 13 or len(svc._free) >= 10
+    assert svc.point_count("S_Employees") == 0 and svc._rows.free_count() == svc.capacity
     assert svc.delete_point("S_Employees", None)[0] == 404
     # freed rows are reused
     svc.insert_point("S_Employees", v, "B", "b", "S")
-    assert svc._next_row <= 13
+    assert max(svc._points) < 13
 
 
 def _same_answers(a, b, tol=2e-3):
@@ -513,18 +513,18 @@ def test_failed_writes_leak_no_rows_and_keep_the_live_collection(tmp_path):
         raise RuntimeError("device write failed")
 
     svc.gallery.upsert = boom
-    free0, next0 = len(svc._free), svc._next_row
+    free0 = svc._rows.free_count()
     assert svc.insert_point("S_Employees", vecs[0], "q", "q", "S") == (404, {"message": "device write failed"})
-    assert len(svc._free) + (svc.capacity - svc._next_row) == free0 + (svc.capacity - next0)
+    assert svc._rows.free_count() == free0
     svc.gallery.upsert = real_upsert
     svc.gallery.write_f16 = boom
     assert svc.recover_snapshot("S_Employees", path)[0] == 404
     assert svc.point_count("S_Employees") == 6
     assert [svc.search_point("S_Employees", vecs[i], "S") for i in range(6)] == before
-    assert len(svc._free) + (svc.capacity - svc._next_row) == 16 - 6
+    assert svc._rows.free_count() == 16 - 6
     svc.gallery.write_f16 = real_write
     assert svc.recover_snapshot("S_Employees", path)[0] == 200
-    assert svc.point_count("S_Employees") == 6 and len(svc._free) + (svc.capacity - svc._next_row) == 10
+    assert svc.point_count("S_Employees") == 6 and svc._rows.free_count() == 10
     # a snapshot larger than the gallery is refused before anything is dropped
     small = _service(8, 4)
     assert small.recover_snapshot("S_Employees", path)[0] == 404 and small.point_count("S_Employees") == 0
@@ -569,3 +569,30 @@ def test_recognise_batcher_groups_and_isolates_failures():
     assert res[4] == "RuntimeError" and res[5] == "ValueError"
     assert res[6][0] == 404
     assert ctx.calls == [1] * 5          # the refused group call, then one call per request (the refused one records nothing)
+
+
+def test_row_allocator_keeps_a_keys_rows_together():
+    """Rows of one key come from tiles of its own while unclaimed tiles last (a by-key search then
+    reads few tiles); after that rows are borrowed, released rows go back to their tile's owner, and
+    the count of free rows is exact throughout."""
+    from frhot.gallery_service import TILE, _RowAllocator
+    al = _RowAllocator(3 * TILE + 10)
+    assert al.free_count() == 3 * TILE + 10
+    a = [al.alloc(7) for _ in range(5)]
+    b = [al.alloc(9) for _ in range(3)]
+    assert a == [0, 1, 2, 3, 4] and b == [TILE, TILE + 1, TILE + 2]
+    a += [al.alloc(7) for _ in range(TILE)]                      # spills into a second tile of its own
+    assert {r // TILE for r in a} == {0, 2}
+    c = [al.alloc(11) for _ in range(10)]                        # the short last tile
+    assert c == list(range(3 * TILE, 3 * TILE + 10))
+    assert al.free_count() == 3 * TILE + 10 - len(a) - len(b) - len(c)
+    d = al.alloc(11)                                             # every tile is claimed: a borrowed row
+    assert d // TILE in (1, 2) and d not in a + b
+    al.release(a[0])
+    assert al.alloc(7) == a[0]                                   # a released row goes back to its owner
+    al.release(d)
+    free = al.free_count()
+    got = [al.alloc(13) for _ in range(free)]                    # a key without tiles drains everything left
+    assert len(set(got)) == free and not set(got) & set(a + b + c)
+    with pytest.raises(MemoryError):
+        al.alloc(13)
