@@ -264,3 +264,67 @@ def test_config5_rank_shape_keyed_4096_queries(gpu_ctx):
     st_s, st_r = _search_f16(gal, q16, qkeys_sent, k, static=True)
     assert np.array_equal(st_r, got_r) and np.array_equal(st_s, got_s)
     gal.close()
+
+
+def test_config5_rank_shape_collections_stored_together(gpu_ctx):
+    """The same rank share (12.5 M x 512, 2,000 keys, 4,096 keyed queries of top-5) with every
+    collection's rows stored one after the other, as the reference's per-collection storage keeps
+    them (qdrant_database_FE/app.py:108-128): the by-key search reads only each key's tiles and
+    answers exactly as the scan of the whole gallery does; a sample also against the oracle over the
+    key's rows."""
+    import time
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    n, d, bq, k, run, seed = 12_500_000, 512, 4096, 5, 6250, 0xFACE0055
+    nkeys = n // run
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=seed, row0=0, n=n, nkeys=-run, dup_every=100)
+    rng = np.random.default_rng(56)
+    dead = rng.integers(0, n, size=20_000)
+    gal.tombstone(dead)
+    zipf = 1.0 / np.arange(1, nkeys + 1)
+    qkeys = rng.choice(nkeys, size=bq, p=zipf / zipf.sum()).astype(np.int32)
+    targets = qkeys.astype(np.int64) * run + rng.integers(0, run, size=bq)
+    targets = targets[~np.isin(targets, dead)]
+    qkeys = (targets // run).astype(np.int32)
+    t16, tk = gal.read(targets)
+    assert np.array_equal(tk, qkeys)
+    q = _noisy_queries(rng, t16, 0.75).astype(np.float32)
+    qkeys[3] = 5000                                         # nobody has it
+    out, took = {}, {}
+    for mode in (Gallery.SEARCH_WHOLE, Gallery.SEARCH_BY_KEY, Gallery.SEARCH_AUTO):
+        gal.search_mode(mode)
+        gal.search(q[:8], qkeys[:8], k)
+        t0 = time.perf_counter()
+        out[mode] = gal.search(q, qkeys, k)
+        took[mode] = time.perf_counter() - t0
+    print(f"config 5 share, {len(qkeys)} keyed queries over {len(set(qkeys.tolist()))} keys: whole gallery "
+          f"{took[Gallery.SEARCH_WHOLE] * 1e3:.1f} ms, by key {took[Gallery.SEARCH_BY_KEY] * 1e3:.1f} ms, "
+          f"cost rule {took[Gallery.SEARCH_AUTO] * 1e3:.1f} ms")
+    for mode in (Gallery.SEARCH_BY_KEY, Gallery.SEARCH_AUTO):
+        assert np.array_equal(out[mode][1], out[Gallery.SEARCH_WHOLE][1])
+        assert np.array_equal(out[mode][0], out[Gallery.SEARCH_WHOLE][0])
+    got_s, got_r = out[Gallery.SEARCH_BY_KEY]
+    assert (got_r[3] == -1).all() and np.isneginf(got_s[3]).all()
+    live = np.ones(n, bool)
+    live[dead] = False
+    for i in rng.choice(len(qkeys), size=24, replace=False):
+        if i == 3:
+            continue
+        rows = np.arange(qkeys[i] * run, (qkeys[i] + 1) * run)
+        rows = rows[live[rows]]
+        sub16, subk = gal.read(rows)
+        assert (subk == qkeys[i]).all()
+        q16 = osr.unit_rows(q[i:i + 1]).astype(np.float16)
+        ref_s, ref_loc = osr.topk_stored(q16, sub16, k)
+        ref_r = np.where(ref_loc >= 0, rows[np.maximum(ref_loc, 0)], -1)
+        pos = {int(r): j for j, r in enumerate(rows)}
+        qf = q16.astype(np.float32)
+
+        def score(_, row, qf=qf, sub16=sub16, pos=pos):
+            assert row in pos, f"row {row} does not carry the query's key"
+            return float(qf[0] @ sub16[pos[row]].astype(np.float32))
+
+        _check_lists(got_s[i:i + 1], got_r[i:i + 1], ref_s, ref_r, score)
+    assert took[Gallery.SEARCH_BY_KEY] < 0.5 * took[Gallery.SEARCH_WHOLE]
+    gal.close()
