@@ -100,6 +100,8 @@ size_t act_elems(const LayerSpec& l, int B) {
 struct IndexPin {
     int32_t* p = nullptr;
     size_t cap = 0;         // int32 entries
+    hipEvent_t copied = nullptr;    // recorded behind the upload out of `p`; waited for before `p` is written again
+    bool pending = false;
 };
 
 struct frhot_ctx {
@@ -499,6 +501,8 @@ int key_tiles_rebuild(frhot_gallery* g) {
 }
 
 int index_pin_grow(IndexPin& ip, size_t n) {
+    if (!ip.copied) HIP_TRY(hipEventCreateWithFlags(&ip.copied, hipEventDisableTiming));
+    if (ip.pending) { ip.pending = false; HIP_TRY(hipEventSynchronize(ip.copied)); }   // an enqueue-only call's upload
     if (n <= ip.cap) return FRHOT_OK;
     if (ip.p) { int32_t* old = ip.p; ip.p = nullptr; ip.cap = 0; HIP_TRY(hipHostFree(old)); }
     const size_t cap = n + n / 2 + 1024;
@@ -516,12 +520,12 @@ int index_pin_grow(IndexPin& ip, size_t n) {
 // `pin` must stay untouched until the stream has passed this call's copy (the caller's slot or
 // lock guarantees it).  Enqueues only; entered with ctx->mu held.
 int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys, int32_t* qkeys_dev_buf, int Bq, int k,
-                         float* scores_dev, int64_t* rows_dev, IndexPin& pin) {
+                         float* scores_dev, int64_t* rows_dev, IndexPin& pin, int64_t row_base = 0) {
     frhot_ctx* c = g->ctx;
     hipStream_t s = c->stream;
     auto whole = [&]() -> int {
         if (qkeys) HIP_TRY(hipMemcpyAsync(qkeys_dev_buf, qkeys, (size_t)Bq * 4, hipMemcpyHostToDevice, s));
-        return search_enqueue(g, q16, qkeys ? qkeys_dev_buf : nullptr, Bq, k, scores_dev, rows_dev, 0);
+        return search_enqueue(g, q16, qkeys ? qkeys_dev_buf : nullptr, Bq, k, scores_dev, rows_dev, row_base);
     };
     if (!qkeys || g->search_mode == FRHOT_SEARCH_WHOLE || g->key_tiles_off || g->nrows == 0 || Bq <= 0 || k <= 0 ||
         k > 16 || !q16 || !scores_dev || !rows_dev)
@@ -637,6 +641,8 @@ int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys
         if (!gr.tiles->empty()) memcpy(h + o_tiles + gr.toff, gr.tiles->data(), gr.tiles->size() * 4);
     memcpy(h + o_work, work.data(), work.size() * sizeof(ScanWork));
     HIP_TRY(hipMemcpyAsync(g->idx_dev, h, nidx * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(pin.copied, s));
+    pin.pending = true;
     const int32_t* const ord_dev = g->idx_dev;
     HIP_TRY(launch_rows_gather_f16(q16, ord_dev, Bq, g->D, g->q16s, s));
     if (c->stage_begin(3)) return fail(FRHOT_EHIP, "event record failed");
@@ -645,7 +651,7 @@ int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys
                                   (const ScanWork*)(g->idx_dev + o_work), (int)work.size(), s));
     if (c->stage_end(3) || c->stage_begin(4)) return fail(FRHOT_EHIP, "event record failed");
     // every query merges its key's walkers' lists (none: the empty answer) and writes to its caller's row
-    HIP_TRY(launch_topk_final(g->part_s, g->part_r, max_nb, kl, Bq, k, 0, scores_dev, rows_dev, s, ord_dev,
+    HIP_TRY(launch_topk_final(g->part_s, g->part_r, max_nb, kl, Bq, k, row_base, scores_dev, rows_dev, s, ord_dev,
                               g->idx_dev + o_nl));
     if (c->stage_end(4)) return fail(FRHOT_EHIP, "event record failed");
     return FRHOT_OK;
@@ -790,6 +796,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
         if (sl.idx.p) (void)hipHostFree(sl.idx.p);
+        if (sl.idx.copied) (void)hipEventDestroy(sl.idx.copied);
         if (sl.emb_pin) (void)hipHostFree(sl.emb_pin);
         if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -976,6 +983,7 @@ int frhot_gallery_destroy(frhot_gallery* g) {
                     g->q16, g->q32, g->qk, g->out_s, g->out_r, g->mut_rows, g->mut_keys, g->mut_f16, g->idx_dev, g->q16s};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g->idx.p) (void)hipHostFree(g->idx.p);
+    if (g->idx.copied) (void)hipEventDestroy(g->idx.copied);
     delete g;
     return FRHOT_OK;
     });
@@ -1139,6 +1147,26 @@ int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qke
     std::lock_guard<std::mutex> lk(g->ctx->mu);
     DeviceGuard dg(g->ctx->device);
     return search_enqueue(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base);
+    });
+}
+
+int frhot_search_dev_keyed(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_host, int Bq, int k,
+                           void* scores_dev, void* rows_dev, int64_t row_base) {
+    return guarded([&]() -> int {
+    if (!g) return fail(FRHOT_EINVAL, "gallery is null");
+    if (Bq <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "Bq %d / k %d out of range (k <= 16)", Bq, k);
+    if (qkeys_host)
+        for (int i = 0; i < Bq; ++i)
+            if (qkeys_host[i] < 0 && qkeys_host[i] != FRHOT_KEY_ANY)
+                return fail(FRHOT_EINVAL, "query key %d of query %d is neither a row key nor FRHOT_KEY_ANY", qkeys_host[i], i);
+    std::lock_guard<std::mutex> lk(g->ctx->mu);
+    DeviceGuard dg(g->ctx->device);
+    if (qkeys_host) {
+        const int rc = gallery_grow_query_staging(g, Bq);       // the device copy of the keys for a whole-gallery scan
+        if (rc) return rc;
+    }
+    return search_keyed_enqueue(g, q_f16_dev, qkeys_host, g->qk, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, g->idx,
+                                row_base);
     });
 }
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "frhot_search": (C.c_int, [_p, _f32p, _i32p, C.c_int, C.c_int, _f32p, _i64p]),
     "frhot_search_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_search_dev_static": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
+    "frhot_search_dev_keyed": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_merge_topk_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),

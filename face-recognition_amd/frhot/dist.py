@@ -24,8 +24,9 @@ import torch.distributed as dist
 class ShardedSearch:
     def __init__(self, world: int, batch: int, dim: int, k: int, device,
                  search_local: Callable, merge: Callable, qdtype=torch.float16, always_exchange: bool = False):
-        """search_local(q_all, scores_out, rows_out): fill [P*B,k] float32 / int64 (global rows, -1 = none).
-        merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
+        """search_local(q_all, scores_out, rows_out[, qkeys_all]): fill [P*B,k] float32 / int64 (global
+        rows, -1 = none); the fourth argument (int32 [P*B], same device) is passed only by calls that
+        carry keys.  merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
         self.P, self.B, self.D, self.k = world, batch, dim, k
         self.search_local, self.merge = search_local, merge
         # always_exchange: run the gathers and the merge even with one rank (a rehearsal of the
@@ -45,14 +46,24 @@ class ShardedSearch:
             self.r_all = torch.empty((world, n, k), dtype=torch.int64, device=device)
             self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
             self.out_r = torch.empty((n, k), dtype=torch.int64, device=device)
+            self.k_all = torch.empty(n, dtype=torch.int32, device=device)
 
-    def __call__(self, q_local: torch.Tensor):
-        """q_local [B, D] unit rows of this rank -> (scores [P*B,k], rows [P*B,k]) for every rank's queries."""
+    def __call__(self, q_local: torch.Tensor, qkeys_local: torch.Tensor | None = None):
+        """q_local [B, D] unit rows of this rank (and, for a search inside collections, their int32
+        keys [B] on the same device; every rank then passes keys) -> (scores [P*B,k], rows [P*B,k])
+        for every rank's queries.  Keys cost one more small all-gather."""
         if not self.exchange:
-            self.search_local(q_local, self.s_local, self.r_local)
+            if qkeys_local is None:
+                self.search_local(q_local, self.s_local, self.r_local)
+            else:
+                self.search_local(q_local, self.s_local, self.r_local, qkeys_local)
             return self.s_local, self.r_local
         dist.all_gather_into_tensor(self.q_all, q_local)
-        self.search_local(self.q_all, self.s_local, self.r_local)
+        if qkeys_local is None:
+            self.search_local(self.q_all, self.s_local, self.r_local)
+        else:
+            dist.all_gather_into_tensor(self.k_all, qkeys_local.to(torch.int32).contiguous())
+            self.search_local(self.q_all, self.s_local, self.r_local, self.k_all)
         # the gather output is passed flat (rank-major): gloo rejects the stacked shape
         dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)
         # unpack into the two contiguous [P, P*B, k] arrays the merge reads (two small device copies)

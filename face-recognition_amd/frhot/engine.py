@@ -243,6 +243,17 @@ class Gallery:
         check(self._lib.frhot_search_dev(self._h, C.c_void_p(q_f16_dev), C.c_void_p(qkeys_dev or 0), bq, k,
                                          C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
 
+    def search_dev_keyed(self, q_f16_dev: int, qkeys, bq: int, k: int, scores_dev: int, rows_dev: int,
+                         row_base: int = 0):
+        """search_dev with the queries' keys as a host array (or None): the gallery is then searched
+        by key where that pays (see search_mode).  Enqueues only."""
+        qk = None if qkeys is None else np.ascontiguousarray(qkeys, dtype=np.int32).reshape(-1)
+        if qk is not None and qk.size != bq:
+            raise ValueError(f"{qk.size} keys for {bq} queries")
+        check(self._lib.frhot_search_dev_keyed(self._h, C.c_void_p(q_f16_dev),
+                                               _ptr(qk, C.c_int32) if qk is not None else None, bq, k,
+                                               C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
+
     def search_dev_static(self, q_f16_dev: int, qkeys_dev: int | None, bq: int, k: int, scores_dev: int,
                           rows_dev: int, row_base: int = 0):
         """search_dev without any allocation: the scan's scratch is a static device array."""

@@ -205,6 +205,16 @@ int frhot_search_dev(frhot_gallery* g, const void* q_f16_dev, const int32_t* qke
                      int Bq, int k, void* scores_dev, void* rows_dev, int64_t row_base);
 
 /*
+ * frhot_search_dev with the queries' keys in HOST memory (the queries and the answers stay on the
+ * device): the form a row-sharded search uses when its queries carry keys, because with the keys
+ * on the host the shard is searched by key (see frhot_gallery_search_mode).  Enqueues only.
+ * Keys as for frhot_search (other negative values than FRHOT_KEY_ANY: FRHOT_EINVAL); null = none.
+ * Replaces: client.search on one collection (qdrant_database_FE/app.py:316-337) for one shard.
+ */
+int frhot_search_dev_keyed(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_host, int Bq, int k,
+                           void* scores_dev, void* rows_dev, int64_t row_base);
+
+/*
  * frhot_search_dev for callers that cannot allocate (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments, same answer bit for bit; the scan's per-block candidate lists and score

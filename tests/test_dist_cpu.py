@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_rows, dim, batch, k, out_dir):
+def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
     for p in (ROOT, os.path.join(ROOT, "face-recognition_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -43,8 +43,18 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir):
         if rank == 0:
             q_local[0] = g[0]                     # scores exactly 1.0 against rows 0 and n_rows-1
 
-        def search_local(q_all, s_out, r_out):
-            s, r = osr.cosine_topk(q_all.numpy(), shard, k)
+        keys = (np.arange(n_rows) * 7 % 5).astype(np.int32)         # every rank derives the same keys
+        qkeys_local = keys[targets].copy()
+        if rank == 0:
+            qkeys_local[1] = -2                                       # any collection
+            qkeys_local[2] = 77                                       # a collection nobody has
+
+        def search_local(q_all, s_out, r_out, qkeys_all=None):
+            assert (qkeys_all is not None) == keyed
+            if keyed:
+                s, r = osr.cosine_topk(q_all.numpy(), shard, k, keys=keys[base:base + rows], qkeys=qkeys_all.numpy())
+            else:
+                s, r = osr.cosine_topk(q_all.numpy(), shard, k)
             r = np.where(r >= 0, r + base, -1)
             s_out.copy_(torch.from_numpy(s))
             r_out.copy_(torch.from_numpy(r))
@@ -60,8 +70,9 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir):
             out_r.copy_(torch.from_numpy(np.take_along_axis(cr, order, 1)))
 
         ss = ShardedSearch(world, batch, dim, k, torch.device("cpu"), search_local, merge, qdtype=torch.float32)
-        s, r = ss(torch.from_numpy(q_local))
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), q=q_local, targets=targets)
+        s, r = ss(torch.from_numpy(q_local), torch.from_numpy(qkeys_local)) if keyed else ss(torch.from_numpy(q_local))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), q=q_local, targets=targets,
+                 qkeys=qkeys_local)
     finally:
         dist.destroy_process_group()
 
@@ -90,6 +101,32 @@ def test_sharded_search_equals_global_search(tmp_path, world, n_rows):
         assert (ref_r[1:, 0] == targets[1:]).mean() > 0.8
     else:
         assert (ref_r[:, n_rows:] == -1).all() and (ref_r[:, :n_rows] >= 0).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_with_keys_equals_global_search(tmp_path, world):
+    """The same with a key per query (the collection it is looked up in): the keys travel with the
+    queries (one more small all-gather) and every shard filters by them; ANY and a key nobody has
+    included."""
+    n_rows, dim, batch, k = 1000, 64, 6, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_rows, dim, batch, k, str(tmp_path), True), nprocs=world, join=True)
+    from frhot import synth
+    from oracle import search as osr
+    g = synth.unit_gallery(seed=123, n=n_rows, d=dim)
+    g[n_rows - 1] = g[0]
+    keys = (np.arange(n_rows) * 7 % 5).astype(np.int32)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    q_all = np.concatenate([o["q"] for o in outs])
+    qk_all = np.concatenate([o["qkeys"] for o in outs])
+    ref_s, ref_r = osr.cosine_topk(q_all, g, k, keys=keys, qkeys=qk_all)
+    for o in outs:
+        assert np.array_equal(o["r"], ref_r)
+        live = ref_r >= 0
+        assert np.abs(o["s"][live] - ref_s[live]).max() < 1e-6 and np.isneginf(o["s"][~live]).all()
+    assert (ref_r[2] == -1).all()
+    rows = ref_r[ref_r >= 0]
+    assert (keys[ref_r[3:][ref_r[3:] >= 0]] == np.repeat(qk_all[3:], k)[(ref_r[3:] >= 0).ravel()]).all() and rows.size
 
 
 def test_shard_rows_cover_everything():

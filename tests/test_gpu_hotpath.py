@@ -441,6 +441,54 @@ def test_recognise_by_key_equals_whole_scan(gpu_ctx):
     gal.close()
 
 
+def test_search_dev_keyed_one_shard(gpu_ctx):
+    """frhot_search_dev_keyed (queries and answers on the device, keys on the host: what a row-sharded
+    search with keys calls on every shard): the same answer by key and over the whole shard, the
+    shard's row base added, two calls in a row without waiting in between."""
+    import torch
+    from frhot import FrhotError, synth
+    from frhot.engine import Gallery
+    n, d, k, base = 9000, 64, 5, 1_000_000
+    g = synth.unit_gallery(seed=14, n=n, d=d)
+    keys = (np.arange(n) // 900).astype(np.int32)
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, keys, np.arange(n))
+    gal.tombstone(np.arange(5, n, 11))
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(15)
+    t = rng.integers(0, n, size=70)
+    t = t[t % 11 != 5]
+    bq = len(t)
+    q16 = torch.from_numpy(g[t].astype(np.float16)).to(dev)
+    qk = keys[t].copy()
+    qk[0] = -2
+    qk[1] = 4000
+    outs = []
+    for mode in (Gallery.SEARCH_WHOLE, Gallery.SEARCH_BY_KEY):
+        gal.search_mode(mode)
+        s1 = torch.empty((bq, k), dtype=torch.float32, device=dev)
+        r1 = torch.empty((bq, k), dtype=torch.int64, device=dev)
+        s2 = torch.empty((8, k), dtype=torch.float32, device=dev)
+        r2 = torch.empty((8, k), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        gal.search_dev_keyed(q16.data_ptr(), qk, bq, k, s1.data_ptr(), r1.data_ptr(), base)
+        gal.search_dev_keyed(q16.data_ptr(), qk[:8], 8, k, s2.data_ptr(), r2.data_ptr(), base)
+        gpu_ctx.sync()
+        outs.append((s1.cpu().numpy(), r1.cpu().numpy(), s2.cpu().numpy(), r2.cpu().numpy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    s1, r1, s2, r2 = outs[1]
+    assert np.array_equal(r2, r1[:8]) and np.array_equal(s2, s1[:8])
+    assert (r1[2:, 0] == t[2:] + base).all() and r1[0, 0] == t[0] + base and (r1[1] == -1).all()
+    live = r1[2:] >= 0
+    assert (keys[(r1[2:] - base)[live]] == np.repeat(qk[2:], k)[live.ravel()]).all()
+    sd = torch.empty((2, k), dtype=torch.float32, device=dev)
+    rd = torch.empty((2, k), dtype=torch.int64, device=dev)
+    with pytest.raises(FrhotError):
+        gal.search_dev_keyed(q16.data_ptr(), np.array([0, -1], np.int32), 2, k, sd.data_ptr(), rd.data_ptr(), 0)
+    gal.close()
+
+
 def test_dead_key_as_query_key_matches_nothing(gpu_ctx):
     """A query key of -1 (the tombstone value) or any other negative key but ANY is no row key:
     the host forms refuse it, the device-pointer form answers with no row at all, so deleted
