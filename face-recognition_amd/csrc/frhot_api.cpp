@@ -198,6 +198,10 @@ struct frhot_gallery {
     IndexPin idx;                   // of frhot_search (a call holds ctx->mu until its copies are done)
     int32_t* idx_dev = nullptr; size_t idx_dev_cap = 0;
     void* q16s = nullptr; size_t q16s_cap = 0;      // the queries in key order
+    // page-locked mirror of a small frhot_search call's queries and answers (up to kSmallSearch
+    // queries): copies out of and into pageable memory cost tens of microseconds each, most of
+    // what a search inside one small collection takes
+    uint8_t* io_pin = nullptr;
 };
 
 namespace {
@@ -983,6 +987,7 @@ int frhot_gallery_destroy(frhot_gallery* g) {
                     g->q16, g->q32, g->qk, g->out_s, g->out_r, g->mut_rows, g->mut_keys, g->mut_f16, g->idx_dev, g->q16s};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g->idx.p) (void)hipHostFree(g->idx.p);
+    if (g->io_pin) (void)hipHostFree(g->io_pin);
     if (g->idx.copied) (void)hipEventDestroy(g->idx.copied);
     delete g;
     return FRHOT_OK;
@@ -1193,6 +1198,8 @@ int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32
     });
 }
 
+constexpr int kSmallSearch = 64;
+
 int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq, int k, float* scores, int64_t* rows) {
     return guarded([&]() -> int {
     if (!g || !q || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
@@ -1207,13 +1214,23 @@ int frhot_search(frhot_gallery* g, const float* q, const int32_t* qkeys, int Bq,
     int rc = gallery_grow_query_staging(g, Bq);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(g->q32, q, (size_t)Bq * g->D * 4, hipMemcpyHostToDevice, s));
+    const size_t qbytes = (size_t)Bq * g->D * 4, sbytes = (size_t)Bq * k * 4, rbytes = (size_t)Bq * k * 8;
+    const bool small = Bq <= kSmallSearch;
+    const size_t pin_q = (size_t)kSmallSearch * g->D * 4, pin_s = (size_t)kSmallSearch * 16 * 4;
+    if (small && !g->io_pin)
+        HIP_TRY(hipHostMalloc((void**)&g->io_pin, pin_q + pin_s + (size_t)kSmallSearch * 16 * 8, hipHostMallocDefault));
+    if (small) memcpy(g->io_pin, q, qbytes);
+    HIP_TRY(hipMemcpyAsync(g->q32, small ? (const void*)g->io_pin : (const void*)q, qbytes, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_f32_to_unit_f16(g->q32, g->q16, Bq, g->D, s));
     rc = search_keyed_enqueue(g, g->q16, qkeys, g->qk, Bq, k, g->out_s, g->out_r, g->idx);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    HIP_TRY(hipMemcpyAsync(scores, g->out_s, (size_t)Bq * k * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(rows, g->out_r, (size_t)Bq * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(small ? (void*)(g->io_pin + pin_q) : (void*)scores, g->out_s, sbytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(small ? (void*)(g->io_pin + pin_q + pin_s) : (void*)rows, g->out_r, rbytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (small) {
+        memcpy(scores, g->io_pin + pin_q, sbytes);
+        memcpy(rows, g->io_pin + pin_q + pin_s, rbytes);
+    }
     return FRHOT_OK;
     });
 }
