@@ -154,11 +154,39 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     }, {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
 
 
-def scan_only(ctx, Gallery, dev, n, d, seed, shapes):
+def keyed_search_leg(gal, n, d, run, bq=64, k=5, iters=20):
+    """Host-call searches (frhot_search: queries in, answers out) of `bq` queries that each look inside
+    a collection of their own (`run` rows stored together), over the whole gallery and by key."""
+    rng = np.random.default_rng(17)
+    nkeys = n // run
+    qkeys = rng.choice(nkeys, size=bq, replace=False).astype(np.int32)
+    rows = qkeys.astype(np.int64) * run + rng.integers(0, run, size=bq)
+    q16, rk = gal.read(rows)
+    q = q16.astype(np.float32)
+    res = {}
+    for name, mode in (("whole_gallery", gal.SEARCH_WHOLE), ("by_key", gal.SEARCH_BY_KEY)):
+        gal.search_mode(mode)
+        for _ in range(3):
+            s, r = gal.search(q, qkeys, k)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            s, r = gal.search(q, qkeys, k)
+        res[name] = ((time.perf_counter() - t0) / iters * 1e3, s, r)
+    gal.search_mode(gal.SEARCH_AUTO)
+    return {"workload": f"frhot_search, {bq} queries in {bq} collections of {run} rows, {n}x{d} gallery of {nkeys} "
+                        f"collections, top-{k}, host queries in and host answers out",
+            "ms_whole_gallery": res["whole_gallery"][0], "ms_by_key": res["by_key"][0],
+            "same_answers": bool(np.array_equal(res["whole_gallery"][2], res["by_key"][2])
+                                 and np.array_equal(res["whole_gallery"][1], res["by_key"][1])),
+            "top1_is_the_asked_row": bool((res["by_key"][2][:, 0] == rows).all() and (rk == qkeys).all())}
+
+
+def scan_only(ctx, Gallery, dev, n, d, seed, shapes, keyed_run=0):
     """Scan-only shapes on one gallery of their own, timed with the library's stream events.
-    shapes: [(queries, k, label, bound, launches)]; returns one roofline object per shape."""
+    shapes: [(queries, k, label, bound, launches)]; returns one roofline object per shape (and, with
+    keyed_run, the gallery's rows carry keys in runs of that many and a keyed-search object follows)."""
     gal = Gallery(ctx, d, n)
-    gal.fill_synthetic(seed=seed, row0=0, n=n, nkeys=0, dup_every=0)
+    gal.fill_synthetic(seed=seed, row0=0, n=n, nkeys=-keyed_run, dup_every=0)
     outs = []
     for bq, k, label, bound, iters in shapes:
         rows16, _ = gal.read(np.arange(bq) * (n // bq))
@@ -187,6 +215,8 @@ def scan_only(ctx, Gallery, dev, n, d, seed, shapes):
                      "mfma_frac": tf / MFMA_PEAK_TFLOPS, "traffic": tr, "traffic_source": src,
                      "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": ms,
                      "queries_per_s": bq / (ms * 1e-3), "top1_is_the_asked_row": ok, "label": label})
+    if keyed_run:
+        outs.append(keyed_search_leg(gal, n, d, keyed_run))
     gal.close()
     return outs
 
@@ -384,16 +414,17 @@ def main():
                         "what": "frhot_recognise from pageable host crops, answers back on the host"}
 
         # Secondary measurements on rank 0: scan-only shapes on galleries of their own.
-        scan64 = scan4096 = scan4096_q64 = None
+        scan64 = scan4096 = scan4096_q64 = keyed = None
         if P == 1 and not args.no_scan64:      # single-GPU measurements: not repeated in the scaling runs
             log("scan-only shapes")
             scan64, = scan_only(ctx, Gallery, dev, 1_000_000, 512, args.seed + 77,
                                 [(64, 10, "BASELINE config 2 (HBM-bound)", "hbm", 20)])
             if not args.no_scan4096:
-                scan4096, scan4096_q64 = scan_only(
+                scan4096, scan4096_q64, keyed = scan_only(
                     ctx, Gallery, dev, 1_000_000, 4096, args.seed + 78,
                     [(256, 5, "BASELINE config 3 at the reference's dimension (ridge)", "hbm", 10),
-                     (64, 5, "the reference's dimension at a serving-sized batch of queries (HBM-bound)", "hbm", 10)])
+                     (64, 5, "the reference's dimension at a serving-sized batch of queries (HBM-bound)", "hbm", 10)],
+                    keyed_run=500)
 
         line = None
         if rank == 0:
@@ -437,6 +468,7 @@ def main():
                 if scan4096 is not None:
                     line["roofline_scan_d4096"] = scan4096
                     line["roofline_scan_d4096_q64"] = scan4096_q64
+                    line["search_inside_collections"] = keyed
             if P == 1 and not rehearse and not args.no_cpu_baseline:
                 log("cpu baseline")
                 base, gates = cpu_baseline(ctx, gal, images, args, rows_local)
