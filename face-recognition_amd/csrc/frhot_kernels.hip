@@ -2140,6 +2140,17 @@ hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M,
     if (M <= 0 || N <= 0 || N % 128 || splitk <= 0 || K % (64 * splitk) || !x || !w || !partial)
         return hipErrorInvalidValue;
     const int kper = K / 64 / splitk;
+    if (M <= 64) {
+        // a small batch: 64-row tiles, so that the step's loads are mostly weights (the 256-row tile
+        // re-reads 32 KiB of clamped batch rows beside every 16 KiB of weights) and three blocks
+        // share a CU.  Every output element sums its K slice in the same order either way.
+        using Small = GemmCore<64, 128, 1, 4, false>;
+        dim3 grid(N / 128, 1, splitk);
+        hipLaunchKernelGGL((fc_splitk_kernel<64, 128, 1, 4>), grid, dim3(256), 2 * Small::SB, s, (const half_t*)x,
+                           (const half_t*)w, partial, M, N, K, kper);
+        FR_CHECK_LAUNCH();
+        return hipSuccess;
+    }
     dim3 grid(N / 128, (M + 255) / 256, splitk);
     hipLaunchKernelGGL((fc_splitk_kernel<256, 128, 2, 2>), grid, dim3(256), 2 * FcCore::SB, s, (const half_t*)x,
                        (const half_t*)w, partial, M, N, K, kper);
