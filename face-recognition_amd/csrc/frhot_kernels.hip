@@ -2091,13 +2091,19 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
     // Ring layers: 256 pixels x 256 channels per tile.  A small batch leaves CUs without a tile
     // (the 14 x 14 layers have 0.77 pixel tiles per face); when at most half of them would get one,
     // the 128-channel tiling (twice the tiles, about 0.6 of the time each) is the faster launch:
-    // 32 faces, 14 x 14 layers 95 -> 62 us each.  Both tilings give bit-identical outputs: the K
-    // order of every output element is the same.
+    // 32 faces, 14 x 14 layers 95 -> 62 us each; at most 32 tiles (a face or a few) take 64-channel
+    // tiles (1 face: the stack 0.45 -> 0.33 ms).  All tilings give bit-identical outputs: the K
+    // order of every output element is the same.  (Replaying a small batch's launches from a
+    // captured graph was measured too: 0.03 ms of 0.6 per call, not kept.)
 #define FR_CONV(HW, CIN, COUT, POOL, OPAD)                                                                   \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD) {         \
         if (attr) {                                                                                           \
-            const hipError_t e = launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 128, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
+            hipError_t e = launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 128, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
+            if (e == hipSuccess)                                                                              \
+                e = launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 64, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
             if (e != hipSuccess) return e;                                                                    \
+        } else if (((long)B * HW * HW + 255) / 256 * (COUT / 256) <= 32) {                                    \
+            return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 64, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
         } else if (((long)B * HW * HW + 255) / 256 * (COUT / 256) <= 128) {                                   \
             return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 128, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
         }                                                                                                     \
