@@ -66,12 +66,6 @@ void scan_set_bound_min_tiles(int tiles);   // blocks that walk fewer tiles scan
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
                             float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s);
-// The same over the `ntl` 256-row tiles listed in `tile_list` (device memory, tile numbers of the
-// whole gallery; row numbers in the answer stay those of the whole gallery) instead of all tiles.
-hipError_t launch_scan_topk_tiles(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
-                                  const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,
-                                  float* part_s, int64_t* part_r, unsigned* qbound, int* nblk_out, hipStream_t s,
-                                  const int32_t* tile_list, int64_t ntl);
 // One block's share of a search that looks up every key's queries in that key's tiles only.
 struct ScanWork {
     int32_t q0, qend;       // first query of the block's 64-query tile; end of its key's queries

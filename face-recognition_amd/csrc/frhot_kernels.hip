@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
 // Top-k: every lane keeps a sorted list per query column; before a tile's 4*NX new scores are
 // examined, the four lanes that share a query exchange their k-th best: a score below the best
 // of those can never reach the final list.
-template <int K, int RY, int WX, int WY, bool USE_KEYS>
+template <int K, int RY, int WX, int WY, bool USE_KEYS, bool WORK = false>
 __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict__ gal,
                                                            const int32_t* __restrict__ gkeys, long nrows, int D,
                                                            const half_t* __restrict__ q,
@@ -1445,8 +1445,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     // Either a regular grid (nb walkers for each of gridDim.x / nb query tiles, all over the same
     // tiles), or one ScanWork item per block: the query tile, the tile list and the walker number
     // of a search that looks up every key's queries in that key's tiles only.
+    // (WORK is a template parameter so that the regular launches carry none of this.)
     int qtiles, q0, gb, bql = Bq;       // bql: queries at and past this one are not this block's
-    if (work) {
+    if (WORK) {
         const ScanWork w = work[blockIdx.x];
         q0 = w.q0; bql = w.qend; gb = w.gb; nb = w.nb; ntl = w.ntl;
         tile_list = w.tile_off >= 0 ? tile_list + w.tile_off : nullptr;
@@ -1460,7 +1461,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
     const int nk = D / 64;
     // With a tile list the launch scans only the listed 256-row tiles (the tiles that may hold rows
     // of the queries' key), in list order; row numbers stay those of the whole gallery.
-    const long ntiles = tile_list ? ntl : (nrows + 255) / 256;
+    const long ntiles = (WORK && tile_list) ? ntl : (nrows + 255) / 256;
     const long my_tiles = gb < ntiles ? (ntiles - gb + nb - 1) / nb : 0;
     const long S = my_tiles * nk;
     const int cb = ((l7 ^ (lane >> 3)) << 4);
@@ -1491,7 +1492,8 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
         long itile = gb; int iks = 0;   // next gallery step to issue
         int yks = 0;                    // next query slice to issue
         auto issue_x = [&](int slot) __attribute__((always_inline)) {
-            const long ptile = tile_list ? (long)tile_list[itile] : itile;
+            // (uniform index, scalar load: a vector load here would be waited for with everything in flight)
+            const long ptile = (WORK && tile_list) ? (long)tile_list[__builtin_amdgcn_readfirstlane((int)itile)] : itile;
             const char* const base = (const char*)gal + ((size_t)ptile * nk + (size_t)iks) * 32768;
 #pragma unroll
             // with one query tile every gallery byte is read by one CU, once: stream it non-temporally
@@ -1600,7 +1602,7 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #if FR_DBG & 64
                 FR_STAMP(sc_ta);
 #endif
-                const long ptile = tile_list ? (long)tile_list[tile] : tile;
+                const long ptile = (WORK && tile_list) ? (long)tile_list[__builtin_amdgcn_readfirstlane((int)tile)] : tile;
                 const int rbase = (int)(ptile * 256) + wx * TX + g0 * 4;    // rows fit 31 bits (checked at launch)
                 // Rows whose key does not match the query's, and rows past the end of the gallery (last
                 // tile only), are struck out of the accumulators in place (the next tile starts
@@ -2330,7 +2332,7 @@ hipError_t scan_static_scratch(int device, ScanStaticScratch* out) {
     return hipSuccess;
 }
 
-template <int K, int RY, int WX, int WY, bool USE_KEYS>
+template <int K, int RY, int WX, int WY, bool USE_KEYS, bool WORK = false>
 static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q, const int32_t* qkeys,
                             int Bq, int nb, float* part_s, int64_t* part_r, unsigned* qbound, hipStream_t s,
                             bool attr_only, const int32_t* tile_list = nullptr, long ntl = 0,
@@ -2341,7 +2343,7 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     constexpr int merge = RY * WX * 4 * K * 8;
     constexpr int lds = ring > merge ? ring : merge;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS>;
+    auto kern = scan_topk_kernel<K, RY, WX, WY, USE_KEYS, WORK>;
     if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int qtiles = (Bq + RY - 1) / RY;
     hipLaunchKernelGGL(kern, dim3((unsigned)(work ? nwork : nb * qtiles)), dim3(512), lds, s, (const half_t*)g, gk,
@@ -2353,11 +2355,11 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
 
 static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const int32_t* gk, long nrows, int D,
                                 const void* q, const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr,
-                                unsigned* qb, hipStream_t s, bool attr, const int32_t* tl = nullptr, long ntl = 0) {
+                                unsigned* qb, hipStream_t s, bool attr) {
 #define FR_SCAN(K, RY, WX, WY)                                                                              \
     if (kl == K && ry == RY)                                                                                  \
-        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr, tl, ntl)  \
-                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr, tl, ntl);
+        return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr)  \
+                    : scan_inst<K, RY, WX, WY, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr);
     FR_SCAN(5, 64, 4, 2)
     FR_SCAN(5, 128, 4, 2)
     FR_SCAN(5, 256, 2, 4)
@@ -2380,25 +2382,15 @@ size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 1
 hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
                             const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
                             unsigned* qbound, int* nblk_out, hipStream_t s) {
-    return launch_scan_topk_tiles(g, gk, nrows, D, q, qkeys, use_keys, Bq, k, part_s, part_r, qbound, nblk_out, s,
-                                  nullptr, 0);
-}
-
-// The same over the `ntl` tiles listed in `tile_list` (device; 256-row tile numbers, each below
-// the gallery's tile count) instead of all of them; a null list scans the whole gallery.
-hipError_t launch_scan_topk_tiles(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
-                                  const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
-                                  unsigned* qbound, int* nblk_out, hipStream_t s, const int32_t* tile_list,
-                                  int64_t ntl) {
     if (nrows <= 0 || nrows > 0x7fffff00L || D < 64 || D % 64 || Bq <= 0 || k <= 0 || k > 16 || !g || !q ||
-        !part_s || !part_r || !nblk_out || (use_keys && !gk) || (tile_list && ntl <= 0))
+        !part_s || !part_r || !nblk_out || (use_keys && !gk))
         return hipErrorInvalidValue;
     // the kernel addresses the query block and a gallery tile with 32-bit lane offsets
     if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
     const int kl = scan_klist(k);
     const int ry = scan_query_tile(Bq, kl);
     const int qtiles = (Bq + ry - 1) / ry;
-    const long ntiles = tile_list ? (long)ntl : (long)((nrows + 255) / 256);
+    const long ntiles = (nrows + 255) / 256;
     int nb = scan_walkers(qtiles);
     const long nt8 = (ntiles + 7) & ~7L;
     if (nb > nt8) nb = (int)nt8;
@@ -2413,7 +2405,7 @@ hipError_t launch_scan_topk_tiles(const void* g, const int32_t* gk, int64_t nrow
         if (e != hipSuccess) return e;
     }
     return scan_dispatch(kl, ry, use_keys != 0, g, gk, (long)nrows, D, q, qkeys, Bq, nb, part_s, part_r, qbound, s,
-                         false, tile_list, (long)ntl);
+                         false);
 }
 
 // One launch over a list of work items (device memory): block b scans, for the 64-query tile that
@@ -2435,8 +2427,8 @@ hipError_t launch_scan_topk_work(const void* g, const int32_t* gk, int64_t nrows
     }
 #define FR_SCANW(K)                                                                                           \
     if (kl == K)                                                                                              \
-        return scan_inst<K, 64, 4, 2, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r, qbound, s, false, \
-                                            tile_lists, 0, work, nwork);
+        return scan_inst<K, 64, 4, 2, true, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r, qbound, s,  \
+                                                  false, tile_lists, 0, work, nwork);
     FR_SCANW(5)
     FR_SCANW(10)
     FR_SCANW(16)
@@ -2496,7 +2488,13 @@ hipError_t kernels_init() {
                               nullptr, nullptr, true);
             if (e != hipSuccess) return e;
         }
-    return hipSuccess;
+    // the work-list instantiations (search by key)
+    e = scan_inst<5, 64, 4, 2, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    if (e == hipSuccess)
+        e = scan_inst<10, 64, 4, 2, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    if (e == hipSuccess)
+        e = scan_inst<16, 64, 4, 2, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    return e;
 }
 
 }  // namespace frhot
