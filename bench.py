@@ -93,10 +93,11 @@ def cpu_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(ctx, gal, images, args, rows_local):
+def cpu_baseline(ctx, gal, images, args, rows_local, blur_sums=None):
     """Time the CPU oracle on a bounded sample of the same workload (all threads of this job's CPU
-    share, then one thread); also gate correctness of the GPU answer on the same sample."""
-    from oracle import preprocess as op, search as osr, vggface
+    share, then one thread); also gate correctness of the GPU answer on the same sample.
+    blur_sums: the blur-gate leg's device answer for `images`, checked on a few of them."""
+    from oracle import preprocess as op, quality as oq, search as osr, vggface
     from frhot.weights import synthetic_weights
     threads = cpu_threads()
     nf = min(args.cpu_faces, len(images))
@@ -141,6 +142,11 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
     redo = (rows_back.astype(np.float32).reshape(nf, args.k, -1) * q16[:, None, :]).sum(-1)
     ok_scores = bool(np.abs(redo - s_gpu).max() <= 1e-4)
     ok_missed = bool((s_ref[:, 0] <= s_gpu[:, 0] + 1e-4).all() and (s_ref[:, -1] <= s_gpu[:, -1] + 1e-4).all())
+    gates = {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
+    if blur_sums is not None:
+        sample = sorted({0, 1, len(images) // 2, len(images) - 1})
+        gates["blur_sums_equal_oracle"] = all(
+            tuple(int(v) for v in blur_sums[i]) == oq.laplacian_sums(images[i]) for i in sample)
     model, phys, logical = host_cpu_info()
     return {
         "value": 1.0 / (t_embed + t_scan), "unit": "faces/s", "cores": threads, "kind": "port",
@@ -151,7 +157,7 @@ def cpu_baseline(ctx, gal, images, args, rows_local):
         "value_1thread": 1.0 / (t_embed1 + t_scan1), "embed_s_per_face_1thread": t_embed1,
         "scan_s_per_face_1thread": t_scan1,
         "threads": threads, "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
-    }, {"embed_cosine_min": float(cos.min()), "search_scores_ok": ok_scores, "search_no_missed_row": ok_missed}
+    }, gates
 
 
 def keyed_search_leg(gal, n, d, run, bq=64, k=5, iters=20):
@@ -426,6 +432,29 @@ def main():
                      (64, 5, "the reference's dimension at a serving-sized batch of queries (HBM-bound)", "hbm", 10)],
                     keyed_run=500)
 
+        # The check-in blur gate's measure over the same resident crops (not part of the timed step:
+        # the reference applies it to check-in requests only, face_service.py:188-219).
+        blur_leg = blur_sums = None
+        if P == 1 and not args.no_scan64:
+            log("blur gate")
+            sums_dev = torch.empty((B, 2), dtype=torch.int64, device=dev)
+            n_it = 20
+            for _ in range(3):
+                ctx.crop_sharpness_dev(crops_dev.data_ptr(), offsets, hw, strides, sums_dev.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(n_it):
+                ctx.crop_sharpness_dev(crops_dev.data_ptr(), offsets, hw, strides, sums_dev.data_ptr())
+            e1.record(stream)
+            e1.synchronize()
+            us = e0.elapsed_time(e1) / n_it * 1e3
+            crop_bytes = int((hw[:, 0].astype(np.int64) * hw[:, 1] * 3).sum())
+            blur_sums = sums_dev.cpu().numpy()
+            blur_leg = {"kernel": "crop_sharpness_kernel", "bound": "hbm", "us_per_batch": us, "crops": B,
+                        "algorithmic_bytes_per_launch": crop_bytes, "achieved": crop_bytes / us / 1e3,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": crop_bytes / us / 1e3 / HBM_PEAK_GBS,
+                        "what": "Laplacian-variance sums of the batch's crops (memset + kernel), crops resident"}
+
         line = None
         if rank == 0:
             ms_step = elapsed / args.steps * 1e3
@@ -469,9 +498,11 @@ def main():
                     line["roofline_scan_d4096"] = scan4096
                     line["roofline_scan_d4096_q64"] = scan4096_q64
                     line["search_inside_collections"] = keyed
+            if blur_leg is not None:
+                line["blur_gate"] = blur_leg
             if P == 1 and not rehearse and not args.no_cpu_baseline:
                 log("cpu baseline")
-                base, gates = cpu_baseline(ctx, gal, images, args, rows_local)
+                base, gates = cpu_baseline(ctx, gal, images, args, rows_local, blur_sums)
                 line["cpu_baseline"] = base
                 line["gates"].update(gates)
         gal.close()

@@ -138,6 +138,7 @@ struct frhot_ctx {
         uint8_t* dev = nullptr; size_t dev_cap = 0;
         uint8_t* res_pin = nullptr;                  // [B,16] f32 scores, then [B,16] i64 rows
         float* emb_pin = nullptr;                    // [B,4096], allocated at the first request for descriptors
+        int64_t* sharp_pin = nullptr;                // [B,2] Laplacian sums of the crops
         IndexPin idx;                                // query order / keys / tile lists of a by-key search
         hipEvent_t uploaded = nullptr, done = nullptr;
     } slot[2];
@@ -147,6 +148,7 @@ struct frhot_ctx {
     void* q_dev = nullptr;       // fp16 [B,4096]
     int32_t* qkeys_dev = nullptr;
     float* res_s = nullptr; int64_t* res_r = nullptr;  // [B,16]
+    int64_t* sharp_dev = nullptr;                      // [B,2]
     std::vector<CropMeta> meta_host;
     // timing: per stage a ring of (begin, end) event pairs; n[i] counts recorded pairs
     bool timing = false;
@@ -278,6 +280,32 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
     HIP_TRY(launch_fc_splitk(c->fc6_out, c->w7, c->partial, B, kFcN, kFcN, kFc7Split, s));
     HIP_TRY(launch_fc_reduce_relu_l2(c->partial, c->b7, out_f32, out_q, out_q ? Dq : kFcN, B, kFcN, kFc7Split, s));
     if (c->stage_end(2)) return fail(FRHOT_EHIP, "event record failed");
+    return FRHOT_OK;
+}
+
+// Enqueue the Laplacian sums of B crops (the blur gate's measure) into out_dev ([B,2] int64).
+// `meta_ready`: embed_enqueue of the same crops went before on this stream, c->meta_dev holds them.
+int sharpness_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
+                      const int32_t* strides, int B, int64_t* out_dev, bool meta_ready) {
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    if (!crops_dev || !offsets || !hw || !strides || !out_dev) return fail(FRHOT_EINVAL, "null crop arguments");
+    int max_tiles = 0;
+    for (int i = 0; i < B; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h <= 0 || w <= 0 || h > 16384 || w > 16384 || strides[i] < 3 * w)
+            return fail(FRHOT_EINVAL, "bad crop %d: %dx%d stride %d", i, h, w, strides[i]);
+        const int t = ((w + 255) / 256) * ((h + 15) / 16);
+        if (t > max_tiles) max_tiles = t;
+    }
+    if (!meta_ready) {
+        c->meta_host.assign(B, CropMeta{});
+        for (int i = 0; i < B; ++i) {
+            CropMeta& m = c->meta_host[i];
+            m.offset = offsets[i]; m.h = hw[2 * i]; m.w = hw[2 * i + 1]; m.stride = strides[i];
+        }
+        HIP_TRY(hipMemcpyAsync(c->meta_dev, c->meta_host.data(), sizeof(CropMeta) * B, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(launch_crop_sharpness((const uint8_t*)crops_dev, c->meta_dev, max_tiles, out_dev, B, c->stream));
     return FRHOT_OK;
 }
 
@@ -726,6 +754,7 @@ static int ctx_init(frhot_ctx* c) {
         HIP_TRY(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void**)&sl.res_pin, (size_t)B * 16 * (4 + 8), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&sl.sharp_pin, (size_t)B * 16, hipHostMallocDefault));
     }
     const size_t x0_bytes = (size_t)B * 226 * 226 * 4 * 2;
     HIP_TRY(hipMalloc(&c->x0, x0_bytes));
@@ -745,6 +774,7 @@ static int ctx_init(frhot_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->qkeys_dev, (size_t)B * 4));
     HIP_TRY(hipMalloc((void**)&c->res_s, (size_t)B * 16 * 4));
     HIP_TRY(hipMalloc((void**)&c->res_r, (size_t)B * 16 * 8));
+    HIP_TRY(hipMalloc((void**)&c->sharp_dev, (size_t)B * 16));
     uint8_t lut[512];
     for (int i = 0; i < 256; ++i) {
         lut[i] = (uint8_t)i;
@@ -799,6 +829,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
         if (sl.dev) (void)hipFree(sl.dev);
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.res_pin) (void)hipHostFree(sl.res_pin);
+        if (sl.sharp_pin) (void)hipHostFree(sl.sharp_pin);
         if (sl.idx.p) (void)hipHostFree(sl.idx.p);
         if (sl.idx.copied) (void)hipEventDestroy(sl.idx.copied);
         if (sl.emb_pin) (void)hipHostFree(sl.emb_pin);
@@ -807,7 +838,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial,
-                    c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->w6, c->w7, c->b6, c->b7};
+                    c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->sharp_dev, c->w6, c->w7, c->b6, c->b7};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < kNumConv; ++l) {
         if (c->act[l]) (void)hipFree(c->act[l]);
@@ -928,6 +959,38 @@ int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     });
     if (rc) return rc;
     memcpy(out, lease.sl.emb_pin, (size_t)B * kFcN * 4);
+    return FRHOT_OK;
+    });
+}
+
+int frhot_crop_sharpness_dev(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
+                             const int32_t* strides, int B, void* out_dev) {
+    return guarded([&]() -> int {
+    if (!c) return fail(FRHOT_EINVAL, "ctx is null");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    return sharpness_enqueue(c, crops_dev, offsets, hw, strides, B, (int64_t*)out_dev, false);
+    });
+}
+
+int frhot_crop_sharpness(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, const int32_t* strides, int B,
+                         int64_t* out) {
+    return guarded([&]() -> int {
+    if (!c || !out) return fail(FRHOT_EINVAL, "null argument");
+    if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
+    DeviceGuard dg(c->device);
+    SlotLease lease(c);
+    std::vector<int64_t> offsets; std::vector<int32_t> ps;
+    int rc = stage_crops(c, lease.sl, crops, hw, strides, B, offsets, ps);
+    if (rc) return rc;
+    rc = run_staged(c, lease.sl, [&]() -> int {
+        int r = sharpness_enqueue(c, lease.sl.dev, offsets.data(), hw, ps.data(), B, c->sharp_dev, false);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(lease.sl.sharp_pin, c->sharp_dev, (size_t)B * 16, hipMemcpyDeviceToHost, c->stream));
+        return FRHOT_OK;
+    });
+    if (rc) return rc;
+    memcpy(out, lease.sl.sharp_pin, (size_t)B * 16);
     return FRHOT_OK;
     });
 }
@@ -1249,9 +1312,9 @@ int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_
     });
 }
 
-int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
-                    const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
-                    float* scores, int64_t* rows) {
+static int recognise_impl(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
+                          const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
+                          float* scores, int64_t* rows, int64_t* sharp) {
     return guarded([&]() -> int {
     if (!c || !g || !scores || !rows) return fail(FRHOT_EINVAL, "null argument");
     if (g->ctx != c) return fail(FRHOT_EINVAL, "gallery belongs to another context");
@@ -1278,6 +1341,11 @@ int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops,
         if (r) return r;
         r = search_keyed_enqueue(g, c->q_dev, qkeys, c->qkeys_dev, B, k, c->res_s, c->res_r, sl.idx);
         if (r) return r;
+        if (sharp) {
+            r = sharpness_enqueue(c, sl.dev, offsets.data(), hw, ps.data(), B, c->sharp_dev, true);
+            if (r) return r;
+            HIP_TRY(hipMemcpyAsync(sl.sharp_pin, c->sharp_dev, (size_t)B * 16, hipMemcpyDeviceToHost, s));
+        }
         if (emb_out) HIP_TRY(hipMemcpyAsync(sl.emb_pin, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(pin_s, c->res_s, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(pin_r, c->res_r, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
@@ -1287,8 +1355,22 @@ int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops,
     if (emb_out) memcpy(emb_out, sl.emb_pin, (size_t)B * kFcN * 4);
     memcpy(scores, pin_s, (size_t)B * k * 4);
     memcpy(rows, pin_r, (size_t)B * k * 8);
+    if (sharp) memcpy(sharp, sl.sharp_pin, (size_t)B * 16);
     return FRHOT_OK;
     });
+}
+
+int frhot_recognise(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
+                    const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
+                    float* scores, int64_t* rows) {
+    return recognise_impl(c, g, crops, hw, strides, qkeys, B, flags, k, emb_out, scores, rows, nullptr);
+}
+
+int frhot_recognise_gated(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
+                          const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
+                          float* scores, int64_t* rows, int64_t* sharpness) {
+    if (!sharpness) return guarded([&]() -> int { return fail(FRHOT_EINVAL, "sharpness is null"); });
+    return recognise_impl(c, g, crops, hw, strides, qkeys, B, flags, k, emb_out, scores, rows, sharpness);
 }
 
 int frhot_ctx_timing(frhot_ctx* c, int enable) {

@@ -463,6 +463,156 @@ __global__ __launch_bounds__(256) void normalize_pack_kernel(const uint8_t* __re
     *(half4*)(x0 + (((size_t)b * 226 + oy + 1) * 226 + ox + 1) * 4) = o;
 }
 
+// ------------------------------------------------------------- sharpness ---
+// The check-in blur gate (app/src/utils/legacy.py:125-129): grey = cv2.cvtColor(BGR2GRAY) on uint8
+// (15-bit fixed point: (3735 B + 19235 G + 9798 R + 16384) >> 15), cv2.Laplacian(CV_64F) with its
+// default aperture (up + down + left + right - 4 centre, BORDER_REFLECT_101), then the variance
+// over all pixels.  Every Laplacian value is an integer in [-1020, 1020], so its sum and sum of
+// squares are exact in 64-bit integers: out[b] = {sum, sum of squares} (zero at launch); the host
+// finishes the variance.
+// A wave walks down a strip of image blockIdx.y, 256 pixels wide (four per lane, one 12-byte load
+// per lane and row: the load path moves a wave's request at the same pace whether a lane asks for
+// one byte or sixteen) and 16 rows tall, with the grey values of three rows in registers: every
+// pixel is read once (plus two halo rows per strip), left and right neighbours come from the
+// lanes beside (lanes 0 and 63 read theirs, which is also where the mirrored border falls out of
+// the address), nothing goes through LDS.  Images narrower than four pixels take a plain path.
+FR_DEV int grey_of(unsigned b, unsigned g, unsigned r) { return (int)((b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15); }
+
+struct Px12 { unsigned d0, d1, d2; };
+
+FR_DEV Px12 load12(const uint8_t* p) {
+    Px12 v;
+    __builtin_memcpy(&v, p, 12);
+    return v;
+}
+
+FR_DEV unsigned load4(const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// Four pixels from 12 bytes, shifted down by `skip` whole pixels (the lane that reaches past the
+// row's end loads the row's last 12 bytes instead and drops what belongs to its neighbour).
+FR_DEV void grey4(const Px12 v, int skip, int g[4]) {
+    const int sh = 24 * skip, ws = sh >> 5, s2 = sh & 31;       // 0, 24, 48, 72 bits = whole dwords + 0, 24, 16, 8 bits
+    const unsigned w0 = ws == 0 ? v.d0 : (ws == 1 ? v.d1 : v.d2);
+    const unsigned w1 = ws == 0 ? v.d1 : (ws == 1 ? v.d2 : 0u);
+    const unsigned w2 = ws == 0 ? v.d2 : 0u;
+    const unsigned e0 = (unsigned)((((unsigned long long)w1 << 32) | w0) >> s2);
+    const unsigned e1 = (unsigned)((((unsigned long long)w2 << 32) | w1) >> s2);
+    const unsigned e2 = w2 >> s2;
+    // bytes 0..11 of the shifted run: e0 = bytes 0..3, e1 = bytes 4..7, e2 = bytes 8..11
+    g[0] = grey_of(e0 & 0xff, (e0 >> 8) & 0xff, (e0 >> 16) & 0xff);
+    g[1] = grey_of(e0 >> 24, e1 & 0xff, (e1 >> 8) & 0xff);
+    g[2] = grey_of((e1 >> 16) & 0xff, e1 >> 24, e2 & 0xff);
+    g[3] = grey_of((e2 >> 8) & 0xff, (e2 >> 16) & 0xff, e2 >> 24);
+}
+
+// One pixel from the dword that holds its three bytes (`sh`: their bit offset inside it).
+FR_DEV int grey1(unsigned v, int sh) {
+    v >>= sh;
+    return grey_of(v & 0xff, (v >> 8) & 0xff, (v >> 16) & 0xff);
+}
+
+__global__ __launch_bounds__(256) void crop_sharpness_kernel(const uint8_t* __restrict__ crops,
+                                                             const CropMeta* __restrict__ meta,
+                                                             unsigned long long* __restrict__ out) {
+    constexpr int SW = 256, BH = 16, R = 8;
+    __shared__ long long red[4][2];
+    const int b = blockIdx.y;
+    const long offset = meta[b].offset;
+    const int h = meta[b].h, w = meta[b].w, stride = meta[b].stride;
+    const uint8_t* src = crops + offset;
+    // OpenCV's BORDER_REFLECT_101 for an index in [-1, n]; further out (never used) clamps
+    auto reflect = [](int i, int n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * n - 2 - i;
+        return min(max(i, 0), n - 1);
+    };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long sum = 0, ssq = 0;
+    if (w < 4) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < h * w; i += gridDim.x * 256) {
+            const int y = i / w, x = i - y * w;
+            auto at = [&](int yy, int xx) {
+                const uint8_t* p = src + (size_t)reflect(yy, h) * stride + 3 * reflect(xx, w);
+                return grey_of(p[0], p[1], p[2]);
+            };
+            const int lap = at(y - 1, x) + at(y + 1, x) + at(y, x - 1) + at(y, x + 1) - 4 * at(y, x);
+            sum += lap; ssq += lap * lap;
+        }
+    } else {
+        const int strips = (w + SW - 1) / SW, nitems = strips * ((h + BH - 1) / BH);
+        for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+            const int band = item / strips;
+            const int x = (item - band * strips) * SW + 4 * lane, y0 = band * BH, y1 = min(y0 + BH, h);
+            // this lane's 12 bytes inside a row, pulled back to the row's end where they would overrun it
+            const int xs = min(x, w - 4), skip = min(x - xs, 3);
+            const int o4 = 3 * xs;
+            // the pixel beyond the strip (lane 0: left of its first, lane 63: right of its last)
+            const bool edge = lane == 0 || lane == 63;
+            const int xe = 3 * reflect(lane == 0 ? x - 1 : x + 4, w), oe = min(xe, 3 * w - 4), she = 8 * (xe - oe);
+            const int last = w - 1 - x;                // which of the lane's pixels is the row's last one
+            // R rows at a time, their loads issued before the first is used (the two rows that start
+            // the band go out together with the first R)
+            const Px12 ru = load12(src + (size_t)reflect(y0 - 1, h) * stride + o4);
+            const Px12 rm = load12(src + (size_t)y0 * stride + o4);
+            const unsigned rme = edge ? load4(src + (size_t)y0 * stride + oe) : 0u;
+            int u[4], m[4], me = 0;
+            int s = 0, q = 0;
+            for (int y = y0; y < y1; y += R) {
+                Px12 rd[R];
+                unsigned rde[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint8_t* row = src + (size_t)reflect(y + r + 1, h) * stride;   // past the band: clamped, unused
+                    rd[r] = load12(row + o4);
+                    rde[r] = edge ? load4(row + oe) : 0u;
+                }
+                if (y == y0) {
+                    grey4(ru, skip, u);
+                    grey4(rm, skip, m);
+                    me = grey1(rme, she);
+                }
+                int d[R][4], de[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    grey4(rd[r], skip, d[r]);
+                    de[r] = grey1(rde[r], she);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    int left = __shfl_up(m[3], 1), right = __shfl_down(m[0], 1);
+                    if (lane == 0) left = me;
+                    if (lane == 63) right = me;
+                    const bool live = y + r < y1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lf = j ? m[j - 1] : left;
+                        // the row's last pixel has the pixel to its left on both sides
+                        const int rt = j == last ? lf : (j < 3 ? m[j + 1] : right);
+                        const int lap = u[j] + d[r][j] + lf + rt - 4 * m[j];
+                        if (live && j <= last) { s += lap; q += lap * lap; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { u[j] = m[j]; m[j] = d[r][j]; }
+                    me = de[r];
+                }
+            }
+            sum += s; ssq += q;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); ssq += __shfl_xor(ssq, o); }
+    if (lane == 0) { red[wave][0] = sum; red[wave][1] = ssq; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v != 0) atomicAdd(out + 2 * (size_t)b + threadIdx.x, (unsigned long long)v);
+    }
+}
+
 // --------------------------------------------------------------- gallery ---
 // Gallery rows are kept in HBM in the order the scan streams them: tile by tile (256 rows), and
 // inside a tile 64-component chunk by chunk, so that one K-step's operand (256 rows x 64
@@ -2191,6 +2341,19 @@ hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const ui
     hipError_t e = hipMemsetAsync(out_max, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(resize_u8_kernel, dim3(28, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_crop_sharpness(const uint8_t* crops, const CropMeta* meta, int max_tiles, int64_t* out, int B,
+                                 hipStream_t s) {
+    if (B <= 0 || max_tiles <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)B * 16, s);
+    if (e != hipSuccess) return e;
+    // a block takes four strips at a time; enough blocks for a single large image
+    const int blocks = (max_tiles + 3) / 4, want = B >= 32 ? 64 : 2048 / B;
+    crop_sharpness_kernel<<<dim3(blocks < want ? blocks : want, B), 256, 0, s>>>(crops, meta,
+                                                                                (unsigned long long*)out);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

@@ -50,6 +50,10 @@ SIGNATURES = {
     "frhot_merge_topk_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),
+    "frhot_crop_sharpness": (C.c_int, [_p, _u8pp, _i32p, _i32p, C.c_int, _i64p]),
+    "frhot_crop_sharpness_dev": (C.c_int, [_p, _p, _i64p, _i32p, _i32p, C.c_int, _p]),
+    "frhot_recognise_gated": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
+                                        _f32p, _f32p, _i64p, _i64p]),
     "frhot_ctx_timing": (C.c_int, [_p, C.c_int]),
     "frhot_ctx_stage_ms": (C.c_int, [_p, _f32p]),
 }

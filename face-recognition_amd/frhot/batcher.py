@@ -171,21 +171,24 @@ class RecogniseBatcher(_MicroBatcher):
         self.service = service
         super().__init__(max_batch, max_delay_s, "frhot-recognise-batcher")
 
-    def submit(self, collection_name, crop: np.ndarray, store_id, want_embedding: bool = False) -> Future:
+    def submit(self, collection_name, crop: np.ndarray, store_id, want_embedding: bool = False,
+               want_sharpness: bool = False) -> Future:
         """Queue one crop (uint8 BGR, not gamma-adjusted: the device applies the LUT); the future
-        resolves to (status_code, content, descriptor or None)."""
+        resolves to (status_code, content, descriptor or None), with `want_sharpness` followed by
+        the crop's Laplacian variance (the blur gate's measure, taken before the LUT)."""
         bad = crop_problem(crop)
         if bad is not None:
             fut: Future = Future()
             fut.set_exception(ValueError(bad))
             return fut
-        return self._put((collection_name, crop, store_id, bool(want_embedding)))
+        return self._put((collection_name, crop, store_id, bool(want_embedding), bool(want_sharpness)))
 
     def _dispatch(self, batch):
         reqs = [b[0][:3] for b in batch]
         want = any(b[0][3] for b in batch)
+        sharp = any(b[0][4] for b in batch)
         try:
-            answers = self.service.recognise_points(reqs, want_embeddings=want)
+            answers = self.service.recognise_points(reqs, want_embeddings=want, want_sharpness=sharp)
             self.batches += 1
         except Exception as e:
             if len(batch) == 1:
@@ -196,7 +199,8 @@ class RecogniseBatcher(_MicroBatcher):
             answers = []
             for b in batch:         # one at a time: only the request the library refuses fails
                 try:
-                    answers.append(self.service.recognise_points([b[0][:3]], want_embeddings=b[0][3])[0])
+                    answers.append(self.service.recognise_points([b[0][:3]], want_embeddings=b[0][3],
+                                                                 want_sharpness=sharp)[0])
                 except Exception as e1:
                     answers.append(e1)
                 self.batches += 1
@@ -204,5 +208,5 @@ class RecogniseBatcher(_MicroBatcher):
             if isinstance(ans, Exception):
                 b[1].set_exception(ans)
             else:
-                b[1].set_result(ans if b[0][3] else ans[:2] + (None,))
+                b[1].set_result(ans[:2] + (ans[2] if b[0][3] else None,) + (ans[3:4] if b[0][4] else ()))
         self.items += len(batch)

@@ -33,6 +33,18 @@ def _crop_args(images):
     return arrs, ptrs, hw, strides
 
 
+
+def laplacian_variance(sums, hw) -> np.ndarray:
+    """Variance of an integer image from its exact sum and sum of squares: (n*S2 - S1^2) / n^2,
+    evaluated in whole numbers and rounded once (numpy's .var() of the same values agrees to a
+    few units in the last place).  sums: int64 [m, 2]; hw: [m, 2] rows, columns."""
+    out = np.empty(len(sums), dtype=np.float64)
+    for i, ((s1, s2), (h, w)) in enumerate(zip(np.asarray(sums).tolist(), np.asarray(hw).tolist())):
+        n = int(h) * int(w)
+        out[i] = (n * s2 - s1 * s1) / (n * n)
+    return out
+
+
 class Context:
     """One GPU, one stream, one loaded model (frhot_ctx)."""
 
@@ -139,8 +151,9 @@ class Context:
                                              C.c_void_p(out_s_dev), C.c_void_p(out_r_dev)))
 
     def recognise(self, gallery: "Gallery", images, qkeys=None, k: int = 5, gamma: bool = False, flip: bool = True,
-                  want_embeddings: bool = False):
-        """Fused embed -> search.  Returns (scores [n,k], rows [n,k], embeddings or None)."""
+                  want_embeddings: bool = False, want_sharpness: bool = False):
+        """Fused embed -> search.  Returns (scores [n,k], rows [n,k], embeddings or None), and with
+        `want_sharpness` a fourth item: the crops' Laplacian variances (see crop_sharpness)."""
         n = len(images)
         if n > self.max_batch:
             raise ValueError(f"batch {n} exceeds max_batch {self.max_batch}")
@@ -149,11 +162,43 @@ class Context:
         rows = np.empty((n, k), dtype=np.int64)
         emb = np.empty((n, EMBED_DIM), dtype=np.float32) if want_embeddings else None
         qk = None if qkeys is None else np.ascontiguousarray(qkeys, dtype=np.int32)
-        check(self._lib.frhot_recognise(
-            self._h, gallery.handle, ptrs, _ptr(hw, C.c_int32), _ptr(strides, C.c_int32),
-            _ptr(qk, C.c_int32) if qk is not None else None, n, self.flags(gamma, flip), k,
-            _ptr(emb, C.c_float) if emb is not None else None, _ptr(scores, C.c_float), _ptr(rows, C.c_int64)))
-        return scores, rows, emb
+        args = (self._h, gallery.handle, ptrs, _ptr(hw, C.c_int32), _ptr(strides, C.c_int32),
+                _ptr(qk, C.c_int32) if qk is not None else None, n, self.flags(gamma, flip), k,
+                _ptr(emb, C.c_float) if emb is not None else None, _ptr(scores, C.c_float), _ptr(rows, C.c_int64))
+        if not want_sharpness:
+            check(self._lib.frhot_recognise(*args))
+            return scores, rows, emb
+        sums = np.empty((n, 2), dtype=np.int64)
+        check(self._lib.frhot_recognise_gated(*args, _ptr(sums, C.c_int64)))
+        return scores, rows, emb, laplacian_variance(sums, hw)
+
+    def crop_sharpness_sums(self, images) -> np.ndarray:
+        """int64 [n, 2]: sum and sum of squares of the 3x3 Laplacian of every crop's grey image."""
+        n = len(images)
+        out = np.empty((n, 2), dtype=np.int64)
+        for lo in range(0, n, self.max_batch):
+            chunk = images[lo:lo + self.max_batch]
+            arrs, ptrs, hw, strides = _crop_args(chunk)
+            sub = out[lo:lo + len(chunk)]
+            check(self._lib.frhot_crop_sharpness(self._h, ptrs, _ptr(hw, C.c_int32), _ptr(strides, C.c_int32),
+                                                 len(chunk), _ptr(sub, C.c_int64)))
+        return out
+
+    def crop_sharpness_dev(self, crops_dev: int, offsets: np.ndarray, hw: np.ndarray, strides: np.ndarray,
+                           out_dev: int):
+        """Device-pointer form (arguments as embed_dev); out_dev: int64 [n, 2].  Enqueues only."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        hw = np.ascontiguousarray(hw, dtype=np.int32)
+        strides = np.ascontiguousarray(strides, dtype=np.int32)
+        check(self._lib.frhot_crop_sharpness_dev(self._h, C.c_void_p(crops_dev), _ptr(offsets, C.c_int64),
+                                                 _ptr(hw, C.c_int32), _ptr(strides, C.c_int32), len(offsets),
+                                                 C.c_void_p(out_dev)))
+
+    def crop_sharpness(self, images) -> np.ndarray:
+        """float64 [n]: cv2.Laplacian(cv2.cvtColor(crop, COLOR_BGR2GRAY), CV_64F).var() of uint8 BGR
+        crops, the measure of the reference's blur gate (app/src/utils/legacy.py:125-129)."""
+        hw = np.array([np.asarray(im).shape[:2] for im in images], dtype=np.int64).reshape(-1, 2)
+        return laplacian_variance(self.crop_sharpness_sums(images), hw)
 
 
 class Gallery:

@@ -2,12 +2,14 @@
 (app/src/services/face_service.py:54-616): same coroutine names, same status
 codes and JSON bodies, with the embedding and the search served by libfrhot.so.
 
-Out of the recognition path and therefore not reproduced: face detection and the
-check-in quality gates (face_service.py:73-219), the anti-spoofing verdict and the
-MinIO image upload.  The service always takes the reference's `is_detect_face=False`
-branch (face_service.py:127-131): the whole decoded image is the face box.
-`image_sink`, if given, receives what the reference would hand to
-ImageProcessor.save_face_image.
+The check-in quality gates (face_service.py:73-219) are applied when the service is built
+with `quality_gates=True`: the blur gate measures on the device; the gates that rest on
+third-party models (head direction, eyes, distance, full face, detection, anti-spoofing)
+run when the host has registered those models with frhot.quality.install_models and are
+skipped otherwise.  Without a registered detector the service takes the reference's
+`is_detect_face=False` branch (face_service.py:127-131): the whole decoded image is the
+face box.  The MinIO image upload is not reproduced: `image_sink`, if given, receives what
+the reference would hand to ImageProcessor.save_face_image.
 """
 from __future__ import annotations
 
@@ -22,7 +24,8 @@ from typing import Any, Dict, List, Tuple
 import numpy as np
 from fastapi.responses import JSONResponse
 
-from .legacy import adjust_gamma, check_condition, get_embedding
+from . import quality
+from .legacy import adjust_gamma, check_condition, face_is_real, get_embedding
 
 logger = logging.getLogger(__name__)
 
@@ -56,7 +59,8 @@ def decode_image(img_base64: str) -> np.ndarray:
 
 
 class FaceService:
-    def __init__(self, database_client, image_sink=None, decoder=None, recogniser=None, max_in_flight=None):
+    def __init__(self, database_client, image_sink=None, decoder=None, recogniser=None, max_in_flight=None,
+                 quality_gates=False):
         """`decoder`: base64 string -> pixel array; default decode_image (PIL).  A host with OpenCV
         passes `lambda b: cv2.imdecode(np.frombuffer(base64.b64decode(b), np.uint8), -1)` to decode
         exactly as the reference does."""
@@ -70,6 +74,7 @@ class FaceService:
         # (the reference's limit of 10 bounds CPU threads, face_service.py:43; here it bounds the
         # device batch).
         self.recogniser = recogniser
+        self.quality_gates = bool(quality_gates)
         self._fused_limit = max_in_flight or PROCESSING_SEMAPHORE_LIMIT
         self._fused_sem = None
         self._http_sem = None
@@ -86,70 +91,140 @@ class FaceService:
         if self.image_sink is not None:
             await self.image_sink(data, img, face_id, name, is_checkin)
 
-    async def detect_and_embed_face(self, data, is_detect_face: bool = False,
+    @staticmethod
+    def _refuse(message, status_code=400):
+        return False, JSONResponse(status_code=status_code, content={'status': 2, 'message': message})
+
+    def _locate_face(self, data, img_decode, is_detect_face, is_checkin):
+        """face_service.py:72-176: the gates on the whole image, detection, the choice of the
+        nearest face and the distance gate.  Returns (True, (x1, y1, x2, y2)), (False, response)
+        or (None, None) where the reference hands back "no embedding" (a detector failure
+        outside check-in, face_service.py:125-126)."""
+        have = quality.models_installed() if self.quality_gates else {}
+        if is_checkin and have.get("face_mesh"):
+            ok, message = quality.check_face_left_right(img_decode)
+            if not ok:
+                return self._refuse(message)
+            if not quality.check_eyes_open(img_decode):
+                return self._refuse("Eyes are closed! Please open your eyes")
+        detected = is_detect_face and have.get("extract_faces")
+        if detected:
+            try:
+                boxes, _scores, distances = quality.detect_face(img_decode)
+            except Exception as e:
+                logger.warning(f"{data.store_id} - Error when detecting face: {e}")
+                if is_checkin:
+                    return self._refuse("Error when detecting face! Please try again", 500)
+                return None, None
+        else:
+            boxes, distances = [[0, 0, img_decode.shape[1], img_decode.shape[0]]], [50]   # face_service.py:128-131
+        x, y, w, h = boxes[int(np.argmin(distances))]       # no face: ValueError, answered 500 by the caller
+        x1, y1, x2, y2 = int(x), int(y), int(x + w), int(y + h)
+        if is_checkin and detected:
+            distance = quality.distance_face_to_camera((x1, y1, x2, y2), img_decode.shape[1])
+            if distance < 20:
+                return self._refuse("Face is too close! Please move back")
+            if distance > 70:
+                return self._refuse("Face is too far! Please move forward")
+        return True, (x1, y1, x2, y2)
+
+    def _crop_gates(self, face, is_checkin, sharpness=None):
+        """face_service.py:188-219 on the crop: full face, then blur.  `sharpness`: the crop's
+        Laplacian variance if a fused device call already measured it.  None = passed."""
+        if not (is_checkin and self.quality_gates):
+            return None
+        if sharpness is None and quality.models_installed()["face_detection"]:
+            ok, message = quality.is_full_face(face)
+            if not ok:
+                return self._refuse(message)[1]
+        if sharpness is None:
+            sharpness = quality.laplacian_variance_of(face)
+        if not sharpness >= quality.BLUR_THRESHOLD:
+            return self._refuse("Face is blur! Please keep your face in focus")[1]
+        return None
+
+    async def detect_and_embed_face(self, data, is_detect_face: bool = True,
                                     is_checkin: bool = True) -> Tuple[bool, Any]:
-        """face_service.py:54-273 restricted to decode -> crop -> gamma -> embedding."""
+        """face_service.py:54-273: decode -> gates -> crop -> gamma -> embedding."""
         _, proc = self._sems()
         async with proc:
+            loop = asyncio.get_running_loop()
             try:
                 img_decode = self.decoder(data.img_base64)
-                img_size = img_decode.shape
-                boxes = [[0, 0, img_size[1], img_size[0]]]     # face_service.py:128-131
-                distances = [50]
+                ok, where = await loop.run_in_executor(
+                    self._pool, self._locate_face, data, img_decode, is_detect_face, is_checkin)
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when decoding image: {e}")
-                return False, JSONResponse(status_code=500, content={
-                    'status': 2, 'message': "Error when detecting face! Please try again"})
+                return self._refuse("Error when detecting face! Please try again", 500)
+            if ok is None:
+                return True, (None, img_decode)
+            if not ok:
+                return False, where
             try:
-                idx_large = int(np.argmin(distances))
-                x, y, w, h = boxes[idx_large]
-                x1, y1, x2, y2 = int(x), int(y), int(x + w), int(y + h)
+                x1, y1, x2, y2 = where
                 face = img_decode[y1:y2, x1:x2].astype('uint8')        # face_service.py:180-181
+                refused = await loop.run_in_executor(self._pool, self._crop_gates, face, is_checkin)
+                if refused is not None:
+                    return False, refused
                 face = adjust_gamma(face, gamma=1.5)                   # face_service.py:223
                 try:
-                    loop = asyncio.get_running_loop()
                     emb, is_real = await loop.run_in_executor(self._pool, lambda: get_embedding(face, img_decode))
                     if not is_real and is_checkin:
-                        return False, JSONResponse(status_code=400, content={
-                            'status': 2, 'message': "Face is not real! Please use your real face"})
+                        return self._refuse("Face is not real! Please use your real face")
                 except Exception as e:
                     logger.warning(f"{data.store_id} - Error when encoding face: {e}")
-                    return False, JSONResponse(status_code=500, content={
-                        'status': 2, 'message': "Error! Please try again"})
+                    return self._refuse("Error! Please try again", 500)
                 return True, (emb, img_decode)
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error in face processing: {e}")
-                return False, JSONResponse(status_code=500, content={
-                    'status': 2, 'message': "Error when processing face! Please try again"})
+                return self._refuse("Error when processing face! Please try again", 500)
 
-    def _decode_and_crop(self, data):
-        """face_service.py:65-66,127-131,145-150,180-181 without the gamma LUT (the device applies it)."""
+    def _decode_and_crop(self, data, is_checkin):
+        """face_service.py:65-181 without the gamma LUT (the device applies it): (img_decode, ok,
+        crop or response)."""
         img_decode = self.decoder(data.img_base64)
-        img_size = img_decode.shape
-        x, y, w, h = 0, 0, img_size[1], img_size[0]
-        return img_decode, img_decode[int(y):int(y + h), int(x):int(x + w)].astype('uint8')
+        ok, where = self._locate_face(data, img_decode, True, is_checkin)
+        if not ok:
+            return img_decode, ok, where
+        x1, y1, x2, y2 = where
+        return img_decode, True, img_decode[y1:y2, x1:x2].astype('uint8')
 
-    async def _fused(self, data, collection_name: str, want_embedding: bool):
-        """decode -> crop -> ONE device call (gamma LUT + descriptor + search + vote input).
-        Returns (False, JSONResponse) with the reference's failure bodies, or
-        (True, (embedding or None, img_decode, search_result))."""
+    async def _fused(self, data, collection_name: str, want_embedding: bool, is_checkin: bool = False):
+        """decode -> gates -> crop -> ONE device call (gamma LUT + descriptor + search + vote input,
+        and the blur measure at check-in).  Returns (False, JSONResponse) with the reference's
+        failure bodies, or (True, (embedding or None, img_decode, search_result)); search_result is
+        None where the reference goes on without an embedding."""
         if self._fused_sem is None:
             self._fused_sem = asyncio.Semaphore(self._fused_limit)
         loop = asyncio.get_running_loop()
+        gated = is_checkin and self.quality_gates
         async with self._fused_sem:
             try:
-                img_decode, face = await loop.run_in_executor(self._pool, self._decode_and_crop, data)
+                img_decode, ok, face = await loop.run_in_executor(self._pool, self._decode_and_crop, data, is_checkin)
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when decoding image: {e}")
-                return False, JSONResponse(status_code=500, content={
-                    'status': 2, 'message': "Error when detecting face! Please try again"})
+                return self._refuse("Error when detecting face! Please try again", 500)
+            if ok is None:
+                return True, (None, img_decode, None)        # no embedding (face_service.py:125-126)
+            if not ok:
+                return False, face
             try:
-                fut = self.recogniser.submit(collection_name, face, data.store_id, want_embedding)
-                status, content, emb = await asyncio.wrap_future(fut)
+                if gated and quality.models_installed()["face_detection"]:
+                    ok, message = await loop.run_in_executor(self._pool, quality.is_full_face, face)
+                    if not ok:
+                        return self._refuse(message)
+                fut = self.recogniser.submit(collection_name, face, data.store_id, want_embedding,
+                                             want_sharpness=gated)
+                status, content, emb, *sharp = await asyncio.wrap_future(fut)
+                if gated:
+                    refused = self._crop_gates(face, True, sharpness=sharp[0])
+                    if refused is not None:
+                        return False, refused
+                    if not await loop.run_in_executor(self._pool, face_is_real, img_decode):
+                        return self._refuse("Face is not real! Please use your real face")
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when encoding face: {e}")
-                return False, JSONResponse(status_code=500, content={
-                    'status': 2, 'message': "Error! Please try again"})
+                return self._refuse("Error! Please try again", 500)
         if status == 200 and content.get("message") == "Point found":
             result = {"message": "Point found", "data": [[s, p] for s, p in content.get("data", [])]}
         else:
@@ -201,10 +276,13 @@ class FaceService:
             if self.recogniser is not None:
                 if not await self.database_client.ensure_collections_exist(data.store_id):
                     return JSONResponse(status_code=500, content={'status': 2, 'message': "Error when create collection"})
-                ok, message = await self._fused(data, collection_name, want_embedding=False)
+                ok, message = await self._fused(data, collection_name, want_embedding=False, is_checkin=is_checkin)
                 if not ok:
                     return message
                 _emb, img_decode, search_result = message
+                if search_result is None:
+                    await self._save(data, img_decode, "Unknown", "Unknown")
+                    return JSONResponse(status_code=200, content={'status': 1, 'id': "Unknown", 'name': "Unknown"})
             else:
                 collection_exists, (check_emb, message) = await asyncio.gather(
                     self.database_client.ensure_collections_exist(data.store_id),
@@ -258,6 +336,10 @@ class FaceService:
             if not ok:
                 return message
             emb, img_decode, search_result = message
+            if search_result is None:
+                await self._save(data, img_decode, id_value, name_value, is_checkin=False)
+                return JSONResponse(status_code=200, content={
+                    'status': 1, 'message': f'{verb} face {name_value} with id {id_value} successfully'})
             if not data.is_update and search_result.get('data'):
                 return JSONResponse(status_code=409, content={
                     'status': 0, 'message': "Face is existed! Please use another face"})

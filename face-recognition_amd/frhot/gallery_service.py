@@ -257,13 +257,16 @@ class GalleryService:
 
     NO_KEY = 0x7FFFFFFF      # a query key no row carries: the crop is still embedded, nothing matches
 
-    def recognise_points(self, requests, want_embeddings: bool = False, gamma: bool = True):
+    def recognise_points(self, requests, want_embeddings: bool = False, gamma: bool = True,
+                         want_sharpness: bool = False):
         """Fused form of get_embedding + search_point for a batch: [(collection_name, crop uint8
         [h,w,3] BGR, store_id)] -> [(status, content, descriptor or None)] from ONE frhot_recognise
         call, so the descriptors go from the network to the scan without leaving HBM
         (face_service.py:231-233,275-291 and app.py:300-386 in one step).  `gamma`: apply the
         gamma-1.5 LUT of face_service.py:223 on the device.  Same validation, threshold and vote
-        as search_point; needs a gallery created on a frhot.engine.Context."""
+        as search_point; needs a gallery created on a frhot.engine.Context.  `want_sharpness`: every
+        answer carries a fourth item, the crop's Laplacian variance before the LUT (the measure of
+        the blur gate, legacy.py:125-129), from the same device call."""
         with self._lock:
             out = [None] * len(requests)
             keys, bad = [], {}
@@ -272,9 +275,9 @@ class GalleryService:
                     bad[i] = (404, {"message": "Collection name not found or invalid!"})
                 k = self._keys.get((col, store_id))
                 keys.append(self.NO_KEY if (k is None or i in bad) else k)
-            scores, rows, emb = self.gallery.ctx.recognise(
+            scores, rows, emb, *sharp = self.gallery.ctx.recognise(
                 self.gallery, [r[1] for r in requests], np.asarray(keys, np.int32), SEARCH_LIMIT, gamma=gamma,
-                want_embeddings=want_embeddings)
+                want_embeddings=want_embeddings, want_sharpness=want_sharpness)
             for i in range(len(requests)):
                 e = emb[i].copy() if emb is not None else None
                 if i in bad:
@@ -283,6 +286,8 @@ class GalleryService:
                     out[i] = (200, {"message": "Point not found", "data": []}, e)
                 else:
                     out[i] = (200, vote(self._hits(scores[i], rows[i])), e)
+                if sharp:
+                    out[i] += (float(sharp[0][i]),)
             return out
 
     # -------------------------------------------------------------- snapshots

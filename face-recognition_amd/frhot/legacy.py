@@ -7,8 +7,9 @@ Same names, arguments and return shapes:
 
 get_embedding runs on the GPU through libfrhot.so (via the process-wide engine
 installed with `install_engine`); there is no CPU path.  The reference derives
-`is_real` from a YOLOv8 + anti-spoofing pass (legacy.py:60-74), which is upstream
-of the recognition path and not part of this package: it is reported as True.
+`is_real` from a YOLOv8 + anti-spoofing pass over the whole image (legacy.py:60-74);
+those models are not part of this package: the verdict comes from the detector a host
+registered with frhot.quality.install_models, and is True when there is none.
 """
 from __future__ import annotations
 
@@ -36,7 +37,18 @@ def get_embedding(imgf, imgf_real=None):
         # [1,224,224,4] in the reference and fails there: same outcome, the caller answers 500
         raise ValueError(f"Input img must have 3 channels but it is {imgf.shape}")
     emb = _engine.embed(np.ascontiguousarray(imgf, dtype=np.uint8), gamma=False)
-    return [float(v) for v in emb], True
+    return [float(v) for v in emb], face_is_real(imgf_real)
+
+
+def face_is_real(imgf_real) -> bool:
+    """legacy.py:60-74: the anti-spoofing verdict of the most confident face of the whole image
+    (of the first one when only one was found)."""
+    from . import quality
+    if imgf_real is None or not quality.models_installed()["extract_faces"]:
+        return True
+    faces = quality._extract_faces(imgf_real)
+    best = max(range(len(faces)), key=lambda i: faces[i]['confidence']) if len(faces) > 1 else 0
+    return bool(faces[best]["is_real"])
 
 
 def gamma_table(gamma: float = 1.0) -> np.ndarray:

@@ -252,6 +252,40 @@ int frhot_recognise(frhot_ctx* ctx, frhot_gallery* g, const uint8_t* const* crop
                     unsigned flags, int k, float* emb_out, float* scores, int64_t* rows);
 
 /*
+ * The measure behind the check-in blur gate, for B crops given like frhot_embed's:
+ * out[2i] = sum and out[2i+1] = sum of squares of the 3x3 Laplacian (up + down + left +
+ * right - 4 centre, borders reflected without repeating the edge pixel) of crop i's grey
+ * image (uint8, (3735 B + 19235 G + 9798 R + 16384) >> 15), both exact integers.  With
+ * n = h * w the variance the gate compares is out[2i+1] / n - (out[2i] / n)^2; a crop
+ * passes when that is >= the threshold (100 in the reference's settings).  The gamma LUT
+ * is NOT applied: the reference measures the crop before adjust_gamma.
+ * Replaces: check_detect_blur(img) (app/src/utils/legacy.py:125-129), i.e.
+ * cv2.Laplacian(cv2.cvtColor(img, COLOR_BGR2GRAY), CV_64F).var(), called on the crop at
+ * app/src/services/face_service.py:193.
+ */
+int frhot_crop_sharpness(frhot_ctx* ctx, const uint8_t* const* crops, const int32_t* hw,
+                         const int32_t* strides, int B, int64_t* out);
+
+/*
+ * Same with the pixels already in HBM (arguments as frhot_embed_dev); out_dev is
+ * [B,2] int64 in device memory.  Stream-ordered, does not synchronise.
+ */
+int frhot_crop_sharpness_dev(frhot_ctx* ctx, const void* crops_dev, const int64_t* offsets,
+                             const int32_t* hw, const int32_t* strides, int B, void* out_dev);
+
+/*
+ * frhot_recognise that also returns frhot_crop_sharpness's pairs of the same crops
+ * (sharpness [B,2], host) from the one upload: the caller drops the answers of the crops
+ * that fail the gate.
+ * Replaces: check_detect_blur + get_embedding + search_point of one check-in request
+ * (app/src/services/face_service.py:193,212-219,231-233,275-291).
+ */
+int frhot_recognise_gated(frhot_ctx* ctx, frhot_gallery* g, const uint8_t* const* crops,
+                          const int32_t* hw, const int32_t* strides, const int32_t* qkeys, int B,
+                          unsigned flags, int k, float* emb_out, float* scores, int64_t* rows,
+                          int64_t* sharpness);
+
+/*
  * Stage timing with HIP events on the context stream.  frhot_ctx_timing(ctx, 1)
  * starts (and resets) recording: every later frhot_embed* / frhot_search* call
  * brackets its stages with event pairs (a ring of the last 128 calls) without

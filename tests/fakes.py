@@ -72,8 +72,14 @@ class FakeContext:
         self.embedder = HashEmbedder(dim)
         self.calls = []
 
-    def recognise(self, gallery, images, qkeys=None, k=5, gamma=False, flip=True, want_embeddings=False):
+    def recognise(self, gallery, images, qkeys=None, k=5, gamma=False, flip=True, want_embeddings=False,
+                  want_sharpness=False):
         self.calls.append(len(images))
         emb = np.stack([self.embedder.embed(im, gamma=gamma) for im in images])
         s, r = gallery.search(emb, qkeys, k)
-        return s, r, (emb if want_embeddings else None)
+        out = (s, r, (emb if want_embeddings else None))
+        return out + (self.crop_sharpness(images),) if want_sharpness else out
+
+    def crop_sharpness(self, images):
+        from oracle import quality as oq
+        return np.array([oq.laplacian_var(im) for im in images], np.float64)

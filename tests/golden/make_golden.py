@@ -3,7 +3,8 @@
 None of them comes from running the reference (its packages are not installed
 here and it ships no numeric fixtures): the gamma table evaluates the formula of
 app/src/utils/legacy.py:108-109 directly, the vote cases are worked by hand from
-qdrant_database_FE/app.py:340-384, and the preprocessing / search vectors are
+qdrant_database_FE/app.py:340-384, two blur-gate cases are worked by hand from the
+Laplacian stencil, and the preprocessing / search / blur vectors are
 outputs of this repository's own CPU oracle, kept so that a change of the oracle
 shows up as a diff ("parity unpinned" for those).
 
@@ -63,6 +64,27 @@ def main():
     s, r = osr.cosine_topk(q, g, 5, keys=keys, qkeys=np.array([0, -2, 1], np.int32))
     np.savez_compressed(os.path.join(HERE, "search_oracle.npz"), g=g.astype(np.float16), q=q, keys=keys,
                         qkeys=np.array([0, -2, 1], np.int32), scores=s, rows=r)
+    # blur gate: two cases worked by hand from the stencil and the border rule, then oracle outputs
+    from oracle import quality as oq
+    hand = [
+        # grey 3x3 = [[0,0,0],[0,10,0],[0,0,0]] (B=G=R).  Row -1 and row 3 mirror row 1 (and so the
+        # columns), so an edge pixel next to the centre sees the 10 twice:
+        # Laplacian = [[0,20,0],[20,-40,20],[0,20,0]]
+        {"grey": [[0, 0, 0], [0, 10, 0], [0, 0, 0]], "sum": 40, "sumsq": 3200},
+        # one row [0, 10, 30]: up = down = centre (a single row reflects onto itself); left/right reflect
+        # over the end pixels: lap = [2*0 + 10 + 10 - 0, 2*10 + 0 + 30 - 40, 2*30 + 10 + 10 - 120] = [20, 10, -40]
+        {"grey": [[0, 10, 30]], "sum": -10, "sumsq": 2100},
+    ]
+    with open(os.path.join(HERE, "blur_hand_cases.json"), "w") as f:
+        json.dump(hand, f, indent=1)
+    rng = np.random.default_rng(9)
+    out = {}
+    for i, (h, w) in enumerate([(37, 53), (64, 64), (33, 129), (1, 70), (90, 1)]):
+        c = synth.crop(rng, h, w)
+        out[f"crop{i}"] = c
+        out[f"sums{i}"] = np.array(oq.laplacian_sums(c), np.int64)
+        out[f"var{i}"] = np.float64(oq.laplacian_var(c))
+    np.savez_compressed(os.path.join(HERE, "blur_oracle.npz"), **out)
     print("wrote fixtures to", HERE)
 
 

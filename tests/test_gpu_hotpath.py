@@ -556,6 +556,88 @@ def test_recognise_fused_equals_two_calls(gpu_ctx):
     gal.close()
 
 
+def _blur_crops():
+    from frhot import synth
+    rng = np.random.default_rng(21)
+    shapes = [(1, 1), (1, 2), (2, 1), (2, 2), (1, 300), (300, 1), (31, 63), (32, 64), (33, 65), (64, 128), (65, 129),
+              (7, 1000), (1000, 7), (224, 224), (448, 448), (601, 97), (130, 517), (1500, 1400)]
+    imgs = [synth.crop(rng, h, w) for h, w in shapes]
+    imgs.append(rng.integers(0, 256, (200, 333, 3), dtype=np.uint8))    # white noise: the largest sums per pixel
+    imgs.append(np.zeros((50, 70, 3), np.uint8))
+    imgs.append(np.full((50, 70, 3), 255, np.uint8))
+    chk = np.zeros((96, 96, 3), np.uint8)
+    chk[::2, ::2] = 255
+    chk[1::2, 1::2] = 255
+    imgs.append(chk)                                                    # every Laplacian value is +-1020
+    base = synth.crop(rng, 400, 500)
+    imgs.append(base[13:390:2, 5:480])                                  # strided view: every other row
+    imgs.append(base[:, 100:164])                                       # a column band of a wider image
+    return imgs
+
+
+def test_crop_sharpness_exact(gpu_ctx):
+    """The blur gate's measure (legacy.py:125-129): integer sums bit-exact against the oracle, the
+    variance against numpy's .var() of the oracle's float64 Laplacian, and the gate's decision."""
+    import os
+    from oracle import quality as oq
+    imgs = _blur_crops()
+    sums = gpu_ctx.crop_sharpness_sums(imgs)
+    var = gpu_ctx.crop_sharpness(imgs)
+    for i, im in enumerate(imgs):
+        assert tuple(int(v) for v in sums[i]) == oq.laplacian_sums(im), f"crop {i} {im.shape}"
+        want = oq.laplacian_var(im)
+        assert var[i] == pytest.approx(want, rel=1e-11, abs=1e-9), f"crop {i} {im.shape}"
+        assert bool(var[i] >= 100) == oq.check_detect_blur(im)
+    # one at a time, and in another order, the answers are the same (sums are accumulated by atomics)
+    order = np.random.default_rng(0).permutation(len(imgs))
+    assert np.array_equal(gpu_ctx.crop_sharpness_sums([imgs[i] for i in order]), sums[order])
+    assert np.array_equal(gpu_ctx.crop_sharpness_sums([imgs[5]]), sums[5:6])
+    # the committed fixture and the hand-worked cases, on the device
+    import json
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(golden, "blur_oracle.npz"))
+    got = gpu_ctx.crop_sharpness_sums([z[f"crop{i}"] for i in range(5)])
+    assert np.array_equal(got, np.stack([z[f"sums{i}"] for i in range(5)]))
+    with open(os.path.join(golden, "blur_hand_cases.json")) as f:
+        for case in json.load(f):
+            img = np.repeat(np.array(case["grey"], np.uint8)[:, :, None], 3, axis=2)
+            assert gpu_ctx.crop_sharpness_sums([img]).tolist() == [[case["sum"], case["sumsq"]]]
+
+
+def test_crop_sharpness_dev_and_gated_recognise(gpu_ctx):
+    """The device-pointer form and the fused call give the host call's sums; the fused call's other
+    answers are frhot_recognise's."""
+    import ctypes as C
+    import torch
+    from frhot import synth
+    from frhot._lib import check, load
+    from frhot.engine import Gallery
+    imgs = synth.crops(seed=41, n=6, lo=90, hi=260)
+    want = gpu_ctx.crop_sharpness_sums(imgs)
+    packed, offsets, hw, strides = synth.pack_crops(imgs)
+    dev = torch.from_numpy(packed).cuda()
+    out = torch.full((len(imgs), 2), -7, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    hw = np.ascontiguousarray(hw, np.int32)
+    strides = np.ascontiguousarray(strides, np.int32)
+    check(load().frhot_crop_sharpness_dev(
+        gpu_ctx.handle, C.c_void_p(dev.data_ptr()), offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+        hw.ctypes.data_as(C.POINTER(C.c_int32)), strides.ctypes.data_as(C.POINTER(C.c_int32)), len(imgs),
+        C.c_void_p(out.data_ptr())))
+    gpu_ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), want)
+    g = synth.unit_gallery(seed=42, n=500, d=4096, sparse=True)
+    gal = Gallery(gpu_ctx, 4096, 500)
+    gal.upsert(g, 0, np.arange(500))
+    for gamma in (False, True):
+        s1, r1, e1 = gpu_ctx.recognise(gal, imgs, None, 5, gamma=gamma, want_embeddings=True)
+        s2, r2, e2, var = gpu_ctx.recognise(gal, imgs, None, 5, gamma=gamma, want_embeddings=True, want_sharpness=True)
+        assert np.array_equal(s1, s2) and np.array_equal(r1, r2) and np.array_equal(e1, e2)
+        assert np.array_equal(var, gpu_ctx.crop_sharpness(imgs))       # measured before the LUT either way
+    gal.close()
+
+
 def test_concurrent_host_calls_overlap_safely(gpu_ctx):
     """Host calls from several threads at once (the reference embeds from up to 10 worker threads,
     face_service.py:43,231-233): each goes through one of two staging slots, packing and upload

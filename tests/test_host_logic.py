@@ -249,6 +249,175 @@ def test_handlers_status_table(client):
     assert r.status_code == 500 and r.json()["status"] == 2
 
 
+# ----------------------------------------------------------- quality gates ---
+def _mesh(turn=1.0, ear=0.3):
+    """468 landmarks with the nose tip `turn` times nearer to the left face edge than to the right
+    and both eyes open by aspect ratio `ear`."""
+    from frhot import quality
+    lm = np.full((468, 3), 0.5)
+    lm[234, :2], lm[454, :2] = (0.2, 0.5), (0.8, 0.5)
+    lm[5, :2] = (0.2 + 0.6 / (1.0 + turn), 0.5)
+    for eye, cx in ((quality.LEFT_EYE_LANDMARKS, 0.35), (quality.RIGHT_EYE_LANDMARKS, 0.65)):
+        lm[eye[0], :2], lm[eye[3], :2] = (cx - 0.05, 0.4), (cx + 0.05, 0.4)
+        for top, bottom, dx in ((eye[1], eye[5], -0.02), (eye[2], eye[4], 0.02)):
+            lm[top, :2], lm[bottom, :2] = (cx + dx, 0.4 - 0.05 * ear), (cx + dx, 0.4 + 0.05 * ear)
+    return lm
+
+
+def test_quality_gates_equal_the_oracle():
+    from frhot import quality
+    from oracle import quality as oq
+    rng = np.random.default_rng(5)
+    try:
+        for turn in (0.2, 0.39, 0.41, 1.0, 2.4, 2.6, 7.0):
+            for ear in (0.05, 0.199, 0.2, 0.201, 0.4):
+                lm = _mesh(turn, ear) + rng.normal(0, 1e-4, (468, 3))
+                quality.install_models(face_mesh=lambda img: [lm])
+                assert quality.check_face_left_right(None) == oq.check_face_left_right([lm])
+                assert quality.check_eyes_open(None) == oq.check_eyes_open([lm])
+                assert quality.DetectDirection(lm) == oq.detect_direction(lm)
+                for eye in (quality.LEFT_EYE_LANDMARKS, quality.RIGHT_EYE_LANDMARKS):
+                    assert quality.eye_aspect_ratio(eye, lm) == pytest.approx(oq.eye_aspect_ratio(list(eye), lm), rel=1e-12)
+        assert quality.DetectDirection(_mesh(2.6)) == "right" and quality.DetectDirection(_mesh(1 / 2.6)) == "left"
+        quality.install_models(face_mesh=lambda img: [])
+        assert quality.check_face_left_right(None) == oq.check_face_left_right([]) == (False, "Face not detected! Please try again")
+        assert quality.check_eyes_open(None) is False
+        img = np.zeros((120, 80, 3), np.uint8)
+        for _ in range(200):
+            dets = [rng.uniform(0.0, 1.08, (6, 2)) for _ in range(rng.integers(0, 3))]
+            quality.install_models(face_detection=lambda im: dets)
+            assert quality.is_full_face(img) == oq.is_full_face(img.shape, dets)
+        seen = set()
+        for _ in range(200):
+            faces = [{"confidence": float(rng.choice([0.5, 0.79, 0.8, 0.95])), "is_real": bool(rng.random() < 0.8),
+                      "facial_area": {"x": int(rng.integers(0, 50)), "y": int(rng.integers(0, 50)),
+                                      "w": int(rng.integers(20, 200)), "h": int(rng.integers(20, 200)),
+                                      "left_eye": (1, 2), "right_eye": (3, 4)}} for _ in range(rng.integers(0, 4))]
+            quality.install_models(extract_faces=lambda im: faces)
+            got, want = quality.detect_face(img), oq.detect_face(faces, img.shape[1])
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            seen.add(len(got[0]))
+        assert seen >= {0, 1, 2}
+        assert quality.distance_face_to_camera((10, 0, 110, 0), 640) == oq.distance_face_to_camera((10, 0, 110, 0), 640) \
+            == pytest.approx(14.3 * (4 * 640 / 4.8) / 100)
+        quality.install_models()
+        with pytest.raises(RuntimeError):
+            quality.check_eyes_open(img)
+        with pytest.raises(RuntimeError):
+            quality.check_detect_blur(img)
+    finally:
+        quality.install_models()
+
+
+@pytest.mark.parametrize("mode", ["seams", "fused"])
+def test_check_in_gates_status_table(mode):
+    """face_service.py:73-219,238-245: every gate's refusal, in the reference's order, through both
+    service paths; enrolment and customers (is_checkin False) pass ungated."""
+    from fastapi import FastAPI
+    from fastapi.testclient import TestClient
+    from fakes import FakeContext
+    from frhot import legacy, quality, synth
+    from frhot.api import build_router
+    from frhot.batcher import RecogniseBatcher
+    from frhot.database_client import DatabaseClient
+    from frhot.face_service import FaceService
+    rng = np.random.default_rng(2)
+    sharp = synth.crop(rng, 200, 200)
+    sharp[::2, ::2] = 255 - sharp[::2, ::2]                        # plenty of Laplacian energy
+    blurred = np.full((200, 200, 3), 90, np.uint8)
+    blurred[:, :, 1] += np.arange(200, dtype=np.uint8)[None, :] // 8
+    state = {"mesh": [_mesh()], "faces": None, "dets": [np.full((6, 2), 0.5)]}
+
+    def extract(img):
+        if state["faces"] == "raise":
+            raise ValueError("Face could not be detected")
+        if state["faces"] is not None:
+            return state["faces"]
+        h, w = img.shape[:2]      # a 30-cm-wide face box at 40 cm
+        bw = int(14.3 * (4 * w / 4.8) / 40.0)
+        return [{"confidence": 0.93, "is_real": True,
+                 "facial_area": {"x": (w - bw) // 2, "y": 0, "w": bw, "h": h, "left_eye": None, "right_eye": None}}]
+
+    ctx = FakeContext()
+    legacy.install_engine(HashEmbedder())
+    quality.install_engine(ctx)
+    quality.install_models(face_mesh=lambda im: state["mesh"], face_detection=lambda im: state["dets"], extract_faces=extract)
+    svc = _service(4096, 64)
+    recogniser = None
+    if mode == "fused":
+        svc.gallery.ctx = ctx
+        recogniser = RecogniseBatcher(svc, 16, max_delay_s=0.002)
+    app = FastAPI()
+    app.include_router(build_router(FaceService(DatabaseClient(svc), recogniser=recogniser, max_in_flight=16,
+                                                quality_gates=True), api_key="k"))
+    H = {"X-API-Key": "k"}
+    try:
+        with TestClient(app) as c:
+            def recog(img, role="1"):
+                r = c.post("/face_recog_img_base64", json={"img_base64": _b64(img), "role": role, "store_id": "Q"}, headers=H)
+                return r.status_code, r.json()
+            r = c.post("/create_face_img_base64", headers=H,
+                       json={"img_base64": _b64(sharp), "id": "7", "name": "Ann", "role": "1", "store_id": "Q"})
+            assert r.status_code == 201
+            assert recog(sharp) == (200, {"status": 1, "id": "7", "name": "Ann"})
+            table = [
+                ({"mesh": [_mesh(turn=3.0)]}, sharp, "Face is looking right! Please look straight"),
+                ({"mesh": [_mesh(turn=1 / 3.0)]}, sharp, "Face is looking left! Please look straight"),
+                ({"mesh": []}, sharp, "Face not detected! Please try again"),
+                ({"mesh": [_mesh(ear=0.1)]}, sharp, "Eyes are closed! Please open your eyes"),
+                ({"faces": [{"confidence": 0.9, "is_real": True, "facial_area": {"x": 0, "y": 0, "w": 200, "h": 200}}]},
+                 sharp, "Face is too close! Please move back"),
+                ({"faces": [{"confidence": 0.9, "is_real": True, "facial_area": {"x": 90, "y": 90, "w": 25, "h": 25}}]},
+                 sharp, "Face is too far! Please move forward"),
+                ({"dets": [np.array([[0.5, 0.5], [0.5, 0.5], [0.5, 0.5], [0.5, 1.2], [0.5, 0.5], [0.5, 0.5]])]},
+                 sharp, "Your mouth is not detected! Please show your face"),
+                ({"dets": []}, sharp, "Face is not detected"),
+                ({}, blurred, "Face is blur! Please keep your face in focus"),
+            ]
+            for change, img, message in table:
+                saved = dict(state)
+                state.update(change)
+                assert recog(img) == (400, {"status": 2, "message": message}), message
+                state.update(saved)
+            # detector failure and no usable face at check-in: the reference's 500 bodies
+            state["faces"] = "raise"
+            assert recog(sharp) == (500, {"status": 2, "message": "Error when detecting face! Please try again"})
+            state["faces"] = [{"confidence": 0.5, "is_real": True, "facial_area": {"x": 0, "y": 0, "w": 50, "h": 50}}]
+            assert recog(sharp)[0] == 500                      # argmin of an empty list (face_service.py:147)
+            # the spoof verdict of the whole image (legacy.py:60-74): the most confident face decides
+            state["faces"] = None
+            real_extract = extract
+
+            def spoof_second_pass(img, calls=[0]):
+                calls[0] += 1
+                out = real_extract(img)
+                if calls[0] % 2 == 0:       # first call: detect_face; second: get_embedding's own pass
+                    out = out + [{"confidence": 0.99, "is_real": False, "facial_area": out[0]["facial_area"]}]
+                return out
+            quality.install_models(face_mesh=lambda im: state["mesh"], face_detection=lambda im: state["dets"],
+                                   extract_faces=spoof_second_pass)
+            assert recog(sharp) == (400, {"status": 2, "message": "Face is not real! Please use your real face"})
+            quality.install_models(face_mesh=lambda im: state["mesh"], face_detection=lambda im: state["dets"],
+                                   extract_faces=extract)
+            # customers are not gated (is_checkin False): the blurred image goes through to the search
+            assert recog(blurred, role="0")[0] == 404
+            # enrolment is not gated either, and a detector failure there enrols nothing but answers 200
+            state.update(mesh=[_mesh(turn=5.0)])
+            r = c.post("/create_face_img_base64", headers=H,
+                       json={"img_base64": _b64(blurred), "id": "8", "name": "Bob", "role": "1", "store_id": "Q"})
+            assert r.status_code == 201
+            state["faces"] = "raise"
+            r = c.post("/create_face_img_base64", headers=H,
+                       json={"img_base64": _b64(sharp[:100]), "id": "9", "name": "Cy", "role": "1", "store_id": "Q"})
+            assert r.status_code == 200 and r.json() == {"status": 1, "message": "create face Cy with id 9 successfully"}
+    finally:
+        if recogniser is not None:
+            recogniser.close()
+        legacy.install_engine(None)
+        quality.install_engine(None)
+        quality.install_models()
+
+
 # ------------------------------------------------------- weights / synth ---
 def test_weight_blob_layout(weights_f32):
     from frhot.weights import LAYERS, MAGIC, pack_blob, quantize_fp16

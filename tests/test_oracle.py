@@ -277,3 +277,28 @@ def test_topk_stored_equals_cosine_topk():
     assert list(b_r[0, :3]) == [5, 70_000, 140_000]
     s, r = osr.topk_stored(q16[:2], g16[:3], 5, row0=100)
     assert (r[:, 3:] == -1).all() and np.isneginf(s[:, 3:]).all() and sorted(r[0, :3]) == [100, 101, 102]
+
+
+def test_blur_gate_hand_cases_and_fixture():
+    """The Laplacian stencil and border rule on cases worked by hand, 1-pixel-wide images, the
+    grey conversion's rounding, and the committed oracle outputs."""
+    import json
+    from oracle import quality as oq
+    with open(os.path.join(GOLDEN, "blur_hand_cases.json")) as f:
+        for case in json.load(f):
+            grey = np.array(case["grey"], np.uint8)
+            img = np.repeat(grey[:, :, None], 3, axis=2)      # B = G = R = v  ->  grey v (weights sum to 2^15)
+            assert np.array_equal(oq.bgr2gray(img), grey)
+            assert oq.laplacian_sums(img) == (case["sum"], case["sumsq"])
+            n = grey.size
+            assert oq.laplacian_var(img) == pytest.approx(case["sumsq"] / n - (case["sum"] / n) ** 2, rel=1e-12)
+    # grey weights: 0.114 / 0.587 / 0.299 in 15 bits, round half up
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1], [10, 200, 77]]], np.uint8)
+    assert oq.bgr2gray(px).tolist() == [[29, 150, 76, 1, (10 * 3735 + 200 * 19235 + 77 * 9798 + 16384) >> 15]]
+    assert np.array_equal(oq.bgr2gray(np.dstack([px, np.full((1, 5, 1), 9, np.uint8)])), oq.bgr2gray(px))   # alpha ignored
+    assert oq.laplacian_sums(np.full((1, 1, 3), 200, np.uint8)) == (0, 0)
+    assert oq.check_detect_blur(np.full((40, 40, 3), 128, np.uint8)) is False
+    z = np.load(os.path.join(GOLDEN, "blur_oracle.npz"))
+    for i in range(5):
+        assert oq.laplacian_sums(z[f"crop{i}"]) == tuple(int(v) for v in z[f"sums{i}"])
+        assert oq.laplacian_var(z[f"crop{i}"]) == float(z[f"var{i}"])
