@@ -265,8 +265,8 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
     if (c->stage_begin(0)) return fail(FRHOT_EHIP, "event record failed");
     const uint8_t* lut = c->lut_dev + ((flags & FRHOT_FLAG_GAMMA) ? 256 : 0);
     HIP_TRY(launch_resize_u8((const uint8_t*)crops_dev, c->meta_dev, lut, (flags & FRHOT_FLAG_NOFLIP) ? 0 : 1, c->u8,
-                             c->img_max, B, s));
-    HIP_TRY(launch_normalize_pack(c->u8, c->img_max, c->input_scale, c->x0, B, s));
+                             c->img_max, c->input_scale, c->x0, B, s));
+    HIP_TRY(launch_normalize_pack(c->u8, c->img_max, c->input_scale, c->x0, B, s, true));
     if (c->stage_end(0) || c->stage_begin(1)) return fail(FRHOT_EHIP, "event record failed");
     HIP_TRY(launch_conv1_1(c->x0, c->w[0], c->bias[0], c->act[0], B, s));
     for (int l = 1; l < kNumConv; ++l) {

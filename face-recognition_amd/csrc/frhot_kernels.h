@@ -26,14 +26,17 @@ struct ConvLayerDesc {
     int reverse;  // 1: walk the pixel tiles from the last image to the first (cache reuse across layers)
 };
 
+// Resized bytes, per-image maximum, and the fp16 network input [B,226,226,4] of every image whose
+// maximum exceeds 1; launch_normalize_pack(..., only_undivided = true) afterwards does the others.
 hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const uint8_t* lut,
-                            int flip, uint8_t* out_u8, int* out_max, int B, hipStream_t s);
+                            int flip, uint8_t* out_u8, int* out_max, float scale, void* x0_f16, int B,
+                            hipStream_t s);
 // out[b] = {sum, sum of squares} of the 3x3 Laplacian of crop b's grey image (int64 pairs, device);
 // max_tiles: the largest ceil(w/256) * ceil(h/16) of the batch.
 hipError_t launch_crop_sharpness(const uint8_t* crops, const CropMeta* meta, int max_tiles, int64_t* out, int B,
                                  hipStream_t s);
 hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale,
-                                 void* x0_f16, int B, hipStream_t s);
+                                 void* x0_f16, int B, hipStream_t s, bool only_undivided = false);
 hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y,
                           int B, hipStream_t s);
 // `dump`: >= 1 KiB of device scratch (dead lanes of a partial tile store there).

@@ -367,15 +367,49 @@ __global__ __launch_bounds__(256) void fc_reduce_relu_l2_kernel(const float* __r
 // ------------------------------------------------------------ preprocess ---
 // Stage 1: gamma LUT + channel order + cv2-style INTER_LINEAR (11-bit fixed point)
 // resize + centred zero pad, uint8 in -> uint8 [B,224,224,3] out, plus the per-image
-// maximum byte (DeepFace divides by 255 only when it exceeds 1).
+// maximum byte (DeepFace divides by 255 only when it exceeds 1), plus stage 2's fp16
+// network input for the images where it does.
+// A thread produces four consecutive output pixels (12 bytes, one store).  The two source pixels
+// of a row that a bilinear tap pair or a 2x2 box needs are neighbours, six consecutive bytes: one
+// 8-byte load brings both (the load path moves a wave's request at the same pace whether a lane asks
+// for one byte or eight, and twelve byte loads per output pixel were what bounded this kernel); at the
+// end of a row the load is pulled back inside the row and the value shifted down instead.
+FR_DEV void load_pixel_pair(const uint8_t* row, int sx, int rowbytes, bool same, unsigned& pa, unsigned& pb) {
+    if (rowbytes >= 8) {
+        const int o = min(3 * sx, rowbytes - 8);
+        unsigned long long v;
+        __builtin_memcpy(&v, row + o, 8);
+        v >>= 8 * (3 * sx - o);
+        pa = (unsigned)v & 0xffffffu;
+        pb = same ? pa : (unsigned)(v >> 24) & 0xffffffu;
+    } else {                                            // one or two pixels wide
+        const uint8_t* p = row + 3 * sx;
+        pa = p[0] | (p[1] << 8) | (p[2] << 16);
+        pb = same ? pa : (unsigned)(p[3] | (p[4] << 8) | (p[5] << 16));
+    }
+}
+
 __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ crops,
                                                         const CropMeta* __restrict__ meta,
                                                         const uint8_t* __restrict__ lut_g, int flip,
-                                                        uint8_t* __restrict__ out, int* __restrict__ out_max) {
+                                                        uint8_t* __restrict__ out, int* __restrict__ out_max,
+                                                        float scale, half_t* __restrict__ x0) {
     __shared__ uint8_t lut[256];
     __shared__ int red[4];
+    // Stage 2 in the same pass: the network input of a byte value v in channel c is
+    // (v / 255 * 255 - mean[c]) * scale, a table of 3 x 256 fp16 values built with the IEEE operations
+    // normalize_pack_kernel uses.  DeepFace divides by 255 only when the image's largest byte exceeds
+    // 1, which is known when the whole image is done: this pass assumes it does, and
+    // normalize_pack_kernel then redoes the images where it does not (black ones).
+    __shared__ half_t norm[3][256];
     const int b = blockIdx.y;
     lut[threadIdx.x] = lut_g[threadIdx.x];
+    {
+        const float mean[3] = {91.4953f, 103.8827f, 131.0912f};
+        const float v = __fmul_rn(__fdiv_rn((float)threadIdx.x, 255.0f), 255.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) norm[c][threadIdx.x] = (half_t)__fmul_rn(__fsub_rn(v, mean[c]), scale);
+    }
     // blockIdx.y is uniform, so these become scalar loads
     const long offset = meta[b].offset;
     const int sh = meta[b].h, sw = meta[b].w, stride = meta[b].stride;
@@ -384,52 +418,80 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restric
     const double scale_x = meta[b].scale_x, scale_y = meta[b].scale_y;
     __syncthreads();
     const uint8_t* src = crops + offset;
-    const int c0 = flip ? 2 : 0, c2 = flip ? 0 : 2;
+    const int sh0 = flip ? 16 : 0, sh2 = flip ? 0 : 16;     // bit offset of the source byte behind output channel 0 / 2
     int vmax = 0;
-    // 8 output rows per block, 7 pixels per thread
-    for (int it = 0; it < 7; ++it) {
-        const int p = blockIdx.x * 1792 + it * 256 + threadIdx.x;
-        const int oy = p / 224, ox = p - oy * 224;
-        const int dy = oy - pady, dx = ox - padx;
-        int r0v = 0, r1v = 0, r2v = 0;
-        if (dy >= 0 && dy < dh && dx >= 0 && dx < dw) {
-            if (area2x) {
-                const uint8_t* q0 = src + (size_t)(2 * dy) * stride + 6 * dx;
-                const uint8_t* q1 = q0 + stride;
-                r0v = (lut[q0[c0]] + lut[q0[3 + c0]] + lut[q1[c0]] + lut[q1[3 + c0]] + 2) >> 2;
-                r1v = (lut[q0[1]] + lut[q0[4]] + lut[q1[1]] + lut[q1[4]] + 2) >> 2;
-                r2v = (lut[q0[c2]] + lut[q0[3 + c2]] + lut[q1[c2]] + lut[q1[3 + c2]] + 2) >> 2;
-            } else {
-                float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
-                int sx = (int)floorf(fx);
-                fx -= (float)sx;
-                if (sx < 0) { fx = 0.f; sx = 0; }
-                if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
-                const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
-                const int sx1 = min(sx + 1, sw - 1);
-                float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
-                int sy = (int)floorf(fy);
-                fy -= (float)sy;
-                const int b0 = (int)rintf((1.0f - fy) * 2048.0f), b1 = (int)rintf(fy * 2048.0f);
-                const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-                const uint8_t* q0 = src + (size_t)sy0 * stride;
-                const uint8_t* q1 = src + (size_t)sy1 * stride;
-                const uint8_t* p00 = q0 + 3 * sx; const uint8_t* p01 = q0 + 3 * sx1;
-                const uint8_t* p10 = q1 + 3 * sx; const uint8_t* p11 = q1 + 3 * sx1;
-                auto mix = [&](int c) {
-                    const int s0 = lut[p00[c]] * a0 + lut[p01[c]] * a1;
-                    const int s1 = lut[p10[c]] * a0 + lut[p11[c]] * a1;
-                    return (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
-                };
-                r0v = mix(c0); r1v = mix(1); r2v = mix(c2);
-            }
-        }
-        uint8_t* o = out + ((size_t)b * 224 * 224 + p) * 3;
-        o[0] = (uint8_t)r0v; o[1] = (uint8_t)r1v; o[2] = (uint8_t)r2v;
-        vmax = max(vmax, max(r0v, max(r1v, r2v)));
-    }
+    // 1024 consecutive output pixels per block (49 blocks per image), four per thread; 224 is a
+    // multiple of four, so a thread's pixels share a row
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int oy = p / 224, ox = p - oy * 224;
+    const int dy = oy - pady;
+    unsigned ob[3] = {0u, 0u, 0u};
+    half4 xo[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, __shfl_xor(vmax, o));
+    for (int j = 0; j < 4; ++j) xo[j] = half4{norm[0][0], norm[1][0], norm[2][0], (half_t)0.f};     // padding pixels
+    if (dy >= 0 && dy < dh) {
+        const uint8_t *q0, *q1;
+        int b0 = 0, b1 = 0;
+        if (area2x) {
+            q0 = src + (size_t)(2 * dy) * stride;
+            q1 = q0 + stride;
+        } else {
+            float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+            const int sy = (int)floorf(fy);
+            fy -= (float)sy;
+            b0 = (int)rintf((1.0f - fy) * 2048.0f); b1 = (int)rintf(fy * 2048.0f);
+            q0 = src + (size_t)min(max(sy, 0), sh - 1) * stride;
+            q1 = src + (size_t)min(max(sy + 1, 0), sh - 1) * stride;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dx = ox + j - padx;
+            int r0v = 0, r1v = 0, r2v = 0;
+            if (dx >= 0 && dx < dw) {
+                unsigned p00, p01, p10, p11;
+                if (area2x) {
+                    load_pixel_pair(q0, 2 * dx, 3 * sw, false, p00, p01);
+                    load_pixel_pair(q1, 2 * dx, 3 * sw, false, p10, p11);
+                    auto box = [&](int s) {
+                        return (lut[(p00 >> s) & 0xff] + lut[(p01 >> s) & 0xff] + lut[(p10 >> s) & 0xff] +
+                                lut[(p11 >> s) & 0xff] + 2) >> 2;
+                    };
+                    r0v = box(sh0); r1v = box(8); r2v = box(sh2);
+                } else {
+                    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+                    int sx = (int)floorf(fx);
+                    fx -= (float)sx;
+                    if (sx < 0) { fx = 0.f; sx = 0; }
+                    if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+                    const int a0 = (int)rintf((1.0f - fx) * 2048.0f), a1 = (int)rintf(fx * 2048.0f);
+                    const bool same = sx + 1 > sw - 1;          // the right tap is clamped onto the left one
+                    load_pixel_pair(q0, sx, 3 * sw, same, p00, p01);
+                    load_pixel_pair(q1, sx, 3 * sw, same, p10, p11);
+                    auto mix = [&](int s) {
+                        const int s0 = lut[(p00 >> s) & 0xff] * a0 + lut[(p01 >> s) & 0xff] * a1;
+                        const int s1 = lut[(p10 >> s) & 0xff] * a0 + lut[(p11 >> s) & 0xff] * a1;
+                        return (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                    };
+                    r0v = mix(sh0); r1v = mix(8); r2v = mix(sh2);
+                }
+            }
+            // bytes 3j, 3j+1, 3j+2 of the thread's 12
+            const unsigned long long three = (unsigned long long)(r0v | (r1v << 8) | (r2v << 16)) << (8 * (3 * j % 4));
+            ob[3 * j / 4] |= (unsigned)three;
+            if (3 * j % 4 > 1) ob[3 * j / 4 + 1] |= (unsigned)(three >> 32);
+            vmax = max(vmax, max(r0v, max(r1v, r2v)));
+            xo[j] = half4{norm[0][r0v], norm[1][r1v], norm[2][r2v], (half_t)0.f};
+        }
+    }
+    half_t* xd = x0 + (((size_t)b * 226 + oy + 1) * 226 + ox + 1) * 4;     // 8-byte aligned, 16 from the second pixel on
+    *(half4*)xd = xo[0];
+    *(half8*)(xd + 4) = half8{xo[1][0], xo[1][1], xo[1][2], xo[1][3], xo[2][0], xo[2][1], xo[2][2], xo[2][3]};
+    *(half4*)(xd + 12) = xo[3];
+    uint8_t* o = out + ((size_t)b * 224 * 224 + p) * 3;         // 12 * (pixel group): dword aligned
+    struct Out12 { unsigned a, b, c; };
+    *(Out12*)o = Out12{ob[0], ob[1], ob[2]};
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) vmax = max(vmax, __shfl_xor(vmax, o2));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -440,14 +502,17 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restric
 
 // Stage 2: float conversion (x/255 when the image maximum exceeds 1, *255, minus the
 // VGGFace2 channel means), input scale, fp16, into the interior of [B,226,226,4].
+// only_undivided: resize_u8_kernel has written the input of every image under the assumption
+// that its maximum exceeds 1; only the images where it does not are done (again) here.
 __global__ __launch_bounds__(256) void normalize_pack_kernel(const uint8_t* __restrict__ u8,
                                                              const int* __restrict__ img_max, float scale,
-                                                             half_t* __restrict__ x0) {
+                                                             half_t* __restrict__ x0, int only_undivided) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= 224 * 224) return;
     const uint8_t* s = u8 + ((size_t)b * 224 * 224 + p) * 3;
     const bool div = img_max[b] > 1;
+    if (div && only_undivided) return;          // resize_u8_kernel wrote this image's input already
     const float mean[3] = {91.4953f, 103.8827f, 131.0912f};
     half4 o;
 #pragma unroll
@@ -2336,11 +2401,12 @@ hipError_t launch_fc_reduce_relu_l2(const float* partial, const float* bias, flo
 }
 
 hipError_t launch_resize_u8(const uint8_t* crops, const CropMeta* meta, const uint8_t* lut, int flip, uint8_t* out,
-                            int* out_max, int B, hipStream_t s) {
-    if (B <= 0 || !crops || !meta || !lut || !out || !out_max) return hipErrorInvalidValue;
+                            int* out_max, float scale, void* x0, int B, hipStream_t s) {
+    if (B <= 0 || !crops || !meta || !lut || !out || !out_max || !x0) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(out_max, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(resize_u8_kernel, dim3(28, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(49, B), dim3(256), 0, s, crops, meta, lut, flip, out, out_max,
+                       scale, (half_t*)x0);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
@@ -2358,9 +2424,11 @@ hipError_t launch_crop_sharpness(const uint8_t* crops, const CropMeta* meta, int
     return hipSuccess;
 }
 
-hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale, void* x0, int B, hipStream_t s) {
+hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale, void* x0, int B, hipStream_t s,
+                                 bool only_undivided) {
     if (B <= 0 || !u8 || !img_max || !x0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(normalize_pack_kernel, dim3(196, B), dim3(256), 0, s, u8, img_max, scale, (half_t*)x0);
+    hipLaunchKernelGGL(normalize_pack_kernel, dim3(196, B), dim3(256), 0, s, u8, img_max, scale, (half_t*)x0,
+                       only_undivided ? 1 : 0);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
