@@ -65,12 +65,15 @@ def build_router(face_service, api_key: str = DEFAULT_API_KEY) -> APIRouter:
 
 
 def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002,
-               fused: bool = True) -> FastAPI:
+               fused: bool = True, quality_gates: bool = False) -> FastAPI:
     """A FastAPI app serving the two routes from one GPU context with a loaded model.
     `fused`: requests in flight together share ONE frhot_recognise call each round (crops in,
     voted answers out); False serves through the two seams get_embedding / search_point with one
-    micro-batcher each, as a maintainer who patches only those seams would run it."""
-    from . import legacy
+    micro-batcher each, as a maintainer who patches only those seams would run it.
+    `quality_gates`: employees' recognition requests pass the reference's check-in gates
+    (face_service.py:73-219): blur on this context, the others over the models registered with
+    frhot.quality.install_models."""
+    from . import legacy, quality
     from .batcher import EmbedBatcher, RecogniseBatcher, SearchBatcher
     from .database_client import DatabaseClient
     from .face_service import FaceService
@@ -78,11 +81,13 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
 
     batcher = EmbedBatcher(ctx, max_delay_s=max_delay_s)
     legacy.install_engine(batcher)
+    if quality_gates:
+        quality.install_engine(ctx)
     service = GalleryService(ctx, capacity=capacity)
     search_batcher = SearchBatcher(service, max_delay_s=max_delay_s)
     recogniser = RecogniseBatcher(service, ctx.max_batch, max_delay_s=max_delay_s) if fused else None
     face_service = FaceService(DatabaseClient(service, search_batcher), recogniser=recogniser,
-                               max_in_flight=ctx.max_batch)
+                               max_in_flight=ctx.max_batch, quality_gates=quality_gates)
     app = FastAPI(title="frhot recognition path")
     app.include_router(build_router(face_service, api_key))
     app.state.batcher = batcher
@@ -98,6 +103,8 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
             recogniser.close()
         service.close()
         legacy.install_engine(None)
+        if quality_gates:
+            quality.install_engine(None)
 
     app.state.close = close
     app.router.on_shutdown.append(close)

@@ -876,6 +876,57 @@ def test_api_end_to_end_concurrent_requests(gpu_ctx, fused):
         app.state.close()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_api_check_in_blur_gate_on_the_device(gpu_ctx, fused):
+    """face_service.py:193,212-219 through the routes: a sharp photo of an enrolled employee is
+    recognised, the same photo blurred is refused with the reference's body; the measure comes from
+    the device (with `fused` from the same call that embeds and searches), and customers
+    (is_checkin False) are not gated."""
+    import asyncio
+    import base64
+    import io
+
+    import httpx
+    from PIL import Image, ImageFilter
+
+    from frhot import synth
+    from frhot.api import create_app
+    from oracle import quality as oq
+
+    rng = np.random.default_rng(78)
+    sharp = synth.crop(rng, 240, 200)
+    sharp[::3, ::2] = 255 - sharp[::3, ::2]
+    blurred = np.asarray(Image.fromarray(sharp).filter(ImageFilter.GaussianBlur(4)))
+    assert oq.laplacian_var(sharp) > 100 > oq.laplacian_var(blurred)
+
+    def b64(img):
+        buf = io.BytesIO()
+        Image.fromarray(img[:, :, ::-1]).save(buf, format="PNG")
+        return base64.b64encode(buf.getvalue()).decode()
+
+    app = create_app(gpu_ctx, capacity=256, api_key="k", max_delay_s=0.01, fused=fused, quality_gates=True)
+    H = {"X-API-Key": "k"}
+
+    async def run():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot") as c:
+            for role in ("1", "0"):
+                r = await c.post("/create_face_img_base64", headers=H, json={
+                    "img_base64": b64(sharp), "id": "5", "name": "Eve", "role": role, "store_id": "S"})
+                assert r.status_code == 201, r.text
+            rs = await asyncio.gather(*[c.post("/face_recog_img_base64", headers=H, json={
+                "img_base64": b64(img), "role": role, "store_id": "S"})
+                for img, role in ((sharp, "1"), (blurred, "1"), (blurred, "0"), (sharp, "1"))])
+            assert rs[0].status_code == 200 and rs[0].json() == {"status": 1, "id": "5", "name": "Eve"}, rs[0].text
+            assert rs[1].status_code == 400 and rs[1].json() == {
+                "status": 2, "message": "Face is blur! Please keep your face in focus"}, rs[1].text
+            assert rs[2].status_code in (200, 404)          # not gated; whether the blurred photo still matches is the network's affair
+            assert rs[3].status_code == 200
+    try:
+        asyncio.run(run())
+    finally:
+        app.state.close()
+
+
 def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
     """The multi-rank step (all-gather of queries, shard scan with a row base, all-gathers of the
     shard lists, merge) through a one-rank RCCL group on the library's stream: what one GPU can
