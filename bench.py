@@ -323,7 +323,8 @@ def main():
         def merge(s_all, r_all, out_s, out_r):
             ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, P * B, K, out_s.data_ptr(), out_r.data_ptr())
 
-        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse)
+        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse,
+                                drain_before_exchange=share_gpu)
         last = {}
 
         def step():

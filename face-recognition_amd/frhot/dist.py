@@ -23,7 +23,8 @@ import torch.distributed as dist
 
 class ShardedSearch:
     def __init__(self, world: int, batch: int, dim: int, k: int, device,
-                 search_local: Callable, merge: Callable, qdtype=torch.float16, always_exchange: bool = False):
+                 search_local: Callable, merge: Callable, qdtype=torch.float16, always_exchange: bool = False,
+                 drain_before_exchange: bool = False):
         """search_local(q_all, scores_out, rows_out[, qkeys_all]): fill [P*B,k] float32 / int64 (global
         rows, -1 = none); the fourth argument (int32 [P*B], same device) is passed only by calls that
         carry keys.  merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
@@ -32,6 +33,11 @@ class ShardedSearch:
         # always_exchange: run the gathers and the merge even with one rank (a rehearsal of the
         # multi-rank code path on a single GPU)
         self.exchange = world > 1 or always_exchange
+        # drain_before_exchange: wait on the host for the device before every collective.  Only for
+        # rehearsals in which several ranks share ONE GPU over gloo: there a gather queued behind
+        # pending kernels was seen to stall for minutes (the processes' queues are time-sliced),
+        # while a gather on an idle device completes at once.  One rank per GPU never needs it.
+        self.drain = drain_before_exchange
         n = world * batch
         self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if self.exchange else None
         # A shard's answer travels as ONE buffer: its rows (int64) followed by its scores (float32),
@@ -58,12 +64,16 @@ class ShardedSearch:
             else:
                 self.search_local(q_local, self.s_local, self.r_local, qkeys_local)
             return self.s_local, self.r_local
+        if self.drain:
+            torch.cuda.current_stream().synchronize()
         dist.all_gather_into_tensor(self.q_all, q_local)
         if qkeys_local is None:
             self.search_local(self.q_all, self.s_local, self.r_local)
         else:
             dist.all_gather_into_tensor(self.k_all, qkeys_local.to(torch.int32).contiguous())
             self.search_local(self.q_all, self.s_local, self.r_local, self.k_all)
+        if self.drain:
+            torch.cuda.current_stream().synchronize()
         # the gather output is passed flat (rank-major): gloo rejects the stacked shape
         dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)
         # unpack into the two contiguous [P, P*B, k] arrays the merge reads (two small device copies)
