@@ -2070,7 +2070,9 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
                         const int qq = q0 + wy * TY + y * 16 + l15;
                         // (a lane without a row yet holds -inf: below every real score's key)
                         const unsigned hk = ordered_key(lanes4_max(top[y].s[0]));
-                        if (g0 == 0 && hk > ordered_key(-INFINITY) && hk > mine[y])
+                        // (work-list form: the tile's columns past the key's last query belong to other
+                        // keys' queries, whose bounds this block, scoring them without their key, must not touch)
+                        if (g0 == 0 && (!WORK || qq < bql) && hk > ordered_key(-INFINITY) && hk > mine[y])
                             (void)__hip_atomic_fetch_max(qbound + (size_t)qq * K + myslot, hk, __ATOMIC_RELAXED,
                                                          __HIP_MEMORY_SCOPE_AGENT);
                         if (bk[y] > 1u) {                       // 0: some slot is still empty

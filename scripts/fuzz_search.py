@@ -4,7 +4,7 @@
 Random gallery sizes (1 row to millions), dimensions, query counts, k, key filters with tombstones,
 planted exact duplicates and queries that tie; every case is checked like the GPU tests check
 theirs (identical rows except inside score ties within 2e-5, scores within 2e-5).
-Usage: python scripts/fuzz_search.py [cases] [seed]
+Usage: python scripts/fuzz_search.py [cases] [seed] [first case to run]
 """
 import os
 import sys
@@ -22,7 +22,7 @@ from oracle import search as osr  # noqa: E402
 from test_gpu_hotpath import _check_topk  # noqa: E402
 
 
-def one_case(ctx, rng, case):
+def one_case(ctx, rng, case, skip=False):
     d = int(rng.choice([64, 64, 128, 192, 512]))
     kind = rng.integers(0, 10)
     if kind == 0:
@@ -49,6 +49,13 @@ def one_case(ctx, rng, case):
     q[-1] = g[dup[0, 1]]
     keys = rng.integers(0, int(rng.choice([2, 3, 50])), size=n).astype(np.int32) if with_keys else None
     qkeys = None
+    # every random draw of the case happens before the device is used, so that a later case can be
+    # replayed alone (`first` on the command line) from the same seed
+    dead = rng.integers(0, n, size=max(1, n // 100)) if with_keys else None
+    mode = int(rng.integers(0, 3))
+    if skip:
+        return n, d, bq, k, with_keys
+    print(f"case {case}: n={n} d={d} bq={bq} k={k} keys={with_keys} mode={mode} ...", flush=True)
     gal = Gallery(ctx, d, n)
     try:
         for lo in range(0, n, 200_000):
@@ -57,18 +64,30 @@ def one_case(ctx, rng, case):
         if with_keys:
             qkeys = keys[targets].copy()
             qkeys[::5] = -2
-            dead = rng.integers(0, n, size=max(1, n // 100))
             gal.tombstone(dead)
             keys = keys.copy()
             keys[dead] = -1
-        gal.search_mode(int(rng.integers(0, 3)))      # cost rule / by key / whole gallery: the same answer
+        gal.search_mode(mode)                         # cost rule / by key / whole gallery: the same answer
         got_s, got_r = gal.search(q, qkeys, k)
         ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys, qkeys=qkeys, gallery_dtype=np.float16)
         qn = osr.unit_rows(q).astype(np.float16).astype(np.float32)
 
         def score(i, row):
             return float(qn[i] @ osr.unit_rows(g[row:row + 1]).astype(np.float16).astype(np.float32)[0])
-        _check_topk(got_s, got_r, ref_s, ref_r, score, tol=2e-5)
+        try:
+            _check_topk(got_s, got_r, ref_s, ref_r, score, tol=2e-5)
+        except AssertionError as e:
+            import re
+            m = re.search(r"query (\d+)", str(e))
+            if m:
+                i = int(m.group(1))
+                qk = None if qkeys is None else int(qkeys[i])
+                live = None if keys is None else int((keys == qk).sum()) if qk is not None and qk >= 0 else int((keys >= 0).sum())
+                print(f"FAILED query {i}: key {qk}, live rows with it {live}\n got rows {got_r[i].tolist()}\n got scores "
+                      f"{got_s[i].tolist()}\n ref rows {ref_r[i].tolist()}\n ref scores {ref_s[i].tolist()}", flush=True)
+                if keys is not None:
+                    print(" keys of got rows", [int(keys[r]) if r >= 0 else None for r in got_r[i]], flush=True)
+            raise
     finally:
         gal.close()
     return n, d, bq, k, with_keys
@@ -77,11 +96,14 @@ def one_case(ctx, rng, case):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rng = np.random.default_rng(seed)
     ctx = Context(device=0, max_batch=4)
     t0 = time.time()
     for c in range(cases):
-        desc = one_case(ctx, rng, c)
+        desc = one_case(ctx, rng, c, skip=c < first)
+        if c < first:
+            continue
         print(f"case {c}: n={desc[0]} d={desc[1]} bq={desc[2]} k={desc[3]} keys={desc[4]} ok ({time.time() - t0:.0f} s)", flush=True)
     ctx.close()
     print(f"fuzz_search: {cases} cases passed")

@@ -403,6 +403,41 @@ def test_search_by_key_equals_whole_scan(gpu_ctx):
     gal.close()
 
 
+@pytest.mark.parametrize("k", [1, 5, 10])
+def test_search_by_key_long_walks_with_many_keys_in_one_query_tile(gpu_ctx, k):
+    """Keys strewn over every tile of a gallery long enough that a walker takes 24 tiles and more: the
+    by-key launch then shares score bounds between blocks.  Most keys have one or two of the 64 queries,
+    so every block's 64-query tile also holds queries of OTHER keys, which it scores without their key
+    filter: those columns must not reach the other queries' bounds (a query then lost its answer).
+    Same answers as the whole-gallery scan, and as the oracle."""
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    rng = np.random.default_rng(35)
+    n, d, bq = 109_897, 192, 64
+    g = rng.standard_normal((n, d), dtype=np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    keys = rng.integers(0, 50, size=n).astype(np.int32)
+    targets = rng.integers(0, n, size=bq)
+    q = g[targets] + 0.5 * rng.standard_normal((bq, d), dtype=np.float32) / np.sqrt(d)
+    qkeys = keys[targets].copy()
+    qkeys[::5] = -2
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, keys, np.arange(n))
+    dead = rng.integers(0, n, size=n // 100)
+    gal.tombstone(dead)
+    keys[dead] = -1
+    gal.search_mode(Gallery.SEARCH_WHOLE)
+    s_w, r_w = gal.search(q, qkeys, k)
+    gal.search_mode(Gallery.SEARCH_BY_KEY)
+    s_k, r_k = gal.search(q, qkeys, k)
+    assert np.array_equal(r_k, r_w) and np.array_equal(s_k, s_w)
+    ref_s, ref_r = osr.cosine_topk(q, g, k, keys=keys, qkeys=qkeys, gallery_dtype=np.float16)
+    assert (r_k[:, 0] >= 0).all()
+    assert np.array_equal(r_k >= 0, ref_r >= 0)
+    assert np.abs(np.where(r_k >= 0, s_k - ref_s, 0.0)).max() <= 2e-5
+    gal.close()
+
+
 def test_recognise_by_key_equals_whole_scan(gpu_ctx):
     """The fused call (crops in, answers out) with keys: by key and over the whole gallery give the
     same rows and scores, from two threads at once as well (each call's index arrays travel in its
