@@ -655,11 +655,12 @@ int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys
         HIP_TRY(hipMalloc((void**)&g->part_r, need * sizeof(int64_t)));
         g->part_cap = need;
     }
-    if (long_walks && scan_bound_bytes(Bq) > g->qbound_cap) {
+    // (a key's query tiles start at its first query: the last one's columns run up to 63 past Bq)
+    if (long_walks && scan_bound_bytes(Bq + 64) > g->qbound_cap) {
         HIP_TRY(hipStreamSynchronize(s));
         g->qbound_cap = 0;
         HIP_TRY(free_null(g->qbound));
-        const size_t cap = scan_bound_bytes(Bq + Bq / 2);
+        const size_t cap = scan_bound_bytes(Bq + Bq / 2 + 64);
         HIP_TRY(hipMalloc((void**)&g->qbound, cap));
         g->qbound_cap = cap;
     }

@@ -82,6 +82,7 @@ struct ScanWork {
 // One launch over `nwork` such items; the queries (device, [Bq, D] fp16) are in key order and
 // qkeys holds their keys in the same order.  Candidate lists land at
 // part[(gb * Bq + query) * list length]: part_s / part_r hold (largest nb) * Bq lists.
+// qbound: null, or scan_bound_bytes(Bq + 64) bytes (query tiles start at any query here).
 hipError_t launch_scan_topk_work(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D, const void* q_f16,
                                  const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r,
                                  unsigned* qbound, const int32_t* tile_lists, const ScanWork* work, int nwork,

@@ -2644,7 +2644,9 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
 // One launch over a list of work items (device memory): block b scans, for the 64-query tile that
 // starts at work[b].q0 of the Bq queries, tiles gb, gb + nb, ... of its tile list.  The queries'
 // keys are tested on every row.  Candidate lists land at part[(gb * Bq + query) * scan_klist(k)],
-// so part_s / part_r hold (largest nb) * Bq lists; `qbound` as for launch_scan_topk, or null.
+// so part_s / part_r hold (largest nb) * Bq lists; `qbound`: null, or scan_bound_bytes(Bq + 64) bytes
+// (a key's first query tile starts at the key's first query, not at a multiple of 64, so the last
+// tile's columns reach up to 63 queries past the end and their bounds are read like any other's).
 hipError_t launch_scan_topk_work(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
                                  const int32_t* qkeys, int Bq, int k, float* part_s, int64_t* part_r,
                                  unsigned* qbound, const int32_t* tile_lists, const ScanWork* work, int nwork,
@@ -2655,7 +2657,7 @@ hipError_t launch_scan_topk_work(const void* g, const int32_t* gk, int64_t nrows
     if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
     const int kl = scan_klist(k);
     if (qbound) {
-        hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq), s);
+        hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq + 64), s);
         if (e != hipSuccess) return e;
     }
 #define FR_SCANW(K)                                                                                           \

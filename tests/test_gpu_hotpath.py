@@ -403,17 +403,19 @@ def test_search_by_key_equals_whole_scan(gpu_ctx):
     gal.close()
 
 
-@pytest.mark.parametrize("k", [1, 5, 10])
-def test_search_by_key_long_walks_with_many_keys_in_one_query_tile(gpu_ctx, k):
+@pytest.mark.parametrize("k,bq", [(1, 64), (5, 64), (10, 64), (5, 200), (16, 256)])
+def test_search_by_key_long_walks_with_many_keys_in_one_query_tile(gpu_ctx, k, bq):
     """Keys strewn over every tile of a gallery long enough that a walker takes 24 tiles and more: the
     by-key launch then shares score bounds between blocks.  Most keys have one or two of the 64 queries,
     so every block's 64-query tile also holds queries of OTHER keys, which it scores without their key
     filter: those columns must not reach the other queries' bounds (a query then lost its answer).
+    With 200 or 256 queries the last keys' tiles start near the end of the query block, and their
+    columns past it read bounds too (the table has to reach 63 queries past the block).
     Same answers as the whole-gallery scan, and as the oracle."""
     from frhot.engine import Gallery
     from oracle import search as osr
     rng = np.random.default_rng(35)
-    n, d, bq = 109_897, 192, 64
+    n, d = 109_897, 192
     g = rng.standard_normal((n, d), dtype=np.float32)
     g /= np.linalg.norm(g, axis=1, keepdims=True)
     keys = rng.integers(0, 50, size=n).astype(np.int32)
