@@ -508,24 +508,25 @@ __global__ __launch_bounds__(256) void normalize_pack_kernel(const uint8_t* __re
                                                              const int* __restrict__ img_max, float scale,
                                                              half_t* __restrict__ x0, int only_undivided) {
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= 224 * 224) return;
-    const uint8_t* s = u8 + ((size_t)b * 224 * 224 + p) * 3;
     const bool div = img_max[b] > 1;
     if (div && only_undivided) return;          // resize_u8_kernel wrote this image's input already
     const float mean[3] = {91.4953f, 103.8827f, 131.0912f};
-    half4 o;
+    // (a launch that only redoes the rare undivided images has a few blocks per image, which loop)
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < 224 * 224; p += gridDim.x * 256) {
+        const uint8_t* s = u8 + ((size_t)b * 224 * 224 + p) * 3;
+        half4 o;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float v = (float)s[c];
-        if (div) v = __fdiv_rn(v, 255.0f);
-        v = __fmul_rn(v, 255.0f);
-        v = __fsub_rn(v, mean[c]);
-        o[c] = (half_t)__fmul_rn(v, scale);
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)s[c];
+            if (div) v = __fdiv_rn(v, 255.0f);
+            v = __fmul_rn(v, 255.0f);
+            v = __fsub_rn(v, mean[c]);
+            o[c] = (half_t)__fmul_rn(v, scale);
+        }
+        o[3] = (half_t)0.f;
+        const int oy = p / 224, ox = p % 224;
+        *(half4*)(x0 + (((size_t)b * 226 + oy + 1) * 226 + ox + 1) * 4) = o;
     }
-    o[3] = (half_t)0.f;
-    const int oy = p / 224, ox = p % 224;
-    *(half4*)(x0 + (((size_t)b * 226 + oy + 1) * 226 + ox + 1) * 4) = o;
 }
 
 // ------------------------------------------------------------- sharpness ---
@@ -2429,8 +2430,8 @@ hipError_t launch_crop_sharpness(const uint8_t* crops, const CropMeta* meta, int
 hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float scale, void* x0, int B, hipStream_t s,
                                  bool only_undivided) {
     if (B <= 0 || !u8 || !img_max || !x0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(normalize_pack_kernel, dim3(196, B), dim3(256), 0, s, u8, img_max, scale, (half_t*)x0,
-                       only_undivided ? 1 : 0);
+    hipLaunchKernelGGL(normalize_pack_kernel, dim3(only_undivided ? 4 : 196, B), dim3(256), 0, s, u8, img_max, scale,
+                       (half_t*)x0, only_undivided ? 1 : 0);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
