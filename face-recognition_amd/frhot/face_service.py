@@ -118,14 +118,18 @@ class FaceService:
                 return None, None
         else:
             boxes, distances = [[0, 0, img_decode.shape[1], img_decode.shape[0]]], [50]   # face_service.py:128-131
-        x, y, w, h = boxes[int(np.argmin(distances))]       # no face: ValueError, answered 500 by the caller
-        x1, y1, x2, y2 = int(x), int(y), int(x + w), int(y + h)
-        if is_checkin and detected:
-            distance = quality.distance_face_to_camera((x1, y1, x2, y2), img_decode.shape[1])
-            if distance < 20:
-                return self._refuse("Face is too close! Please move back")
-            if distance > 70:
-                return self._refuse("Face is too far! Please move forward")
+        try:
+            x, y, w, h = boxes[int(np.argmin(distances))]   # no usable face: ValueError (face_service.py:147)
+            x1, y1, x2, y2 = int(x), int(y), int(x + w), int(y + h)
+            if is_checkin and detected:
+                distance = quality.distance_face_to_camera((x1, y1, x2, y2), img_decode.shape[1])
+                if distance < 20:
+                    return self._refuse("Face is too close! Please move back")
+                if distance > 70:
+                    return self._refuse("Face is too far! Please move forward")
+        except Exception as e:                               # the reference's second try block (face_service.py:261-273)
+            logger.warning(f"{data.store_id} - Error in face processing: {e}")
+            return self._refuse("Error when processing face! Please try again", 500)
         return True, (x1, y1, x2, y2)
 
     def _crop_gates(self, face, is_checkin, sharpness=None):

@@ -383,7 +383,7 @@ def test_check_in_gates_status_table(mode):
             state["faces"] = "raise"
             assert recog(sharp) == (500, {"status": 2, "message": "Error when detecting face! Please try again"})
             state["faces"] = [{"confidence": 0.5, "is_real": True, "facial_area": {"x": 0, "y": 0, "w": 50, "h": 50}}]
-            assert recog(sharp)[0] == 500                      # argmin of an empty list (face_service.py:147)
+            assert recog(sharp) == (500, {"status": 2, "message": "Error when processing face! Please try again"})   # argmin of an empty list (face_service.py:147,261-273)
             # the spoof verdict of the whole image (legacy.py:60-74): the most confident face decides
             state["faces"] = None
             real_extract = extract
