@@ -22,11 +22,16 @@ from oracle import search as osr  # noqa: E402
 from test_gpu_hotpath import _check_topk  # noqa: E402
 
 
+DIMS = [64, 64, 128, 192, 512]      # FUZZ_DIMS=64,4096 on the command line's environment replaces them
+
+
 def one_case(ctx, rng, case, skip=False):
-    d = int(rng.choice([64, 64, 128, 192, 512]))
+    d = int(rng.choice(DIMS))
     kind = rng.integers(0, 10)
     if kind == 0:
         n = int(rng.integers(1, 300))
+    elif d == 4096:
+        n = int(rng.integers(300, 40_000))
     elif kind < 6:
         n = int(rng.integers(300, 120_000))
     elif kind < 9:
@@ -37,6 +42,8 @@ def one_case(ctx, rng, case, skip=False):
     bq = int(rng.choice([1, 3, 17, 64, 65, 128, 200, 256, 300, 600, 2100])) if n < 700_000 else int(rng.integers(1, 64))
     if bq > 600 and n * bq > 3e8:
         bq = 600
+    if d == 4096 and bq > 300:
+        bq = 300
     k = int(rng.integers(1, 17))
     with_keys = bool(rng.integers(0, 2))
     g = rng.standard_normal((n, d), dtype=np.float32)
@@ -97,6 +104,8 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if os.environ.get("FUZZ_DIMS"):
+        DIMS[:] = [int(x) for x in os.environ["FUZZ_DIMS"].split(",")]
     rng = np.random.default_rng(seed)
     ctx = Context(device=0, max_batch=4)
     t0 = time.time()
