@@ -727,6 +727,27 @@ def test_errors_are_reported(gpu_ctx):
     s, r = gal.search(np.ones((2, 64), np.float32), None, 5)         # empty gallery
     assert (r == -1).all() and np.isneginf(s).all()
     gal.close()
+    # the blur measure: a crop the embedding refuses (it resizes to nothing) is measured all the same;
+    # bad arguments are refused with the library's codes
+    import ctypes as C
+    from frhot._lib import ECAPACITY, EINVAL, load
+    wide = np.zeros((10, 4000, 3), np.uint8)
+    wide[:, ::2] = 200
+    from oracle import quality as oq
+    assert gpu_ctx.crop_sharpness_sums([wide]).tolist() == [list(oq.laplacian_sums(wide))]
+    lib = load()
+    hw = np.array([[10, 4000]], np.int32)
+    ptr = (C.POINTER(C.c_uint8) * 1)(wide.ctypes.data_as(C.POINTER(C.c_uint8)))
+    out = np.zeros(2, np.int64)
+    i32, i64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    bad_stride = np.array([100], np.int32)          # fewer bytes per row than 3 * w
+    assert lib.frhot_crop_sharpness(gpu_ctx.handle, ptr, hw.ctypes.data_as(i32), bad_stride.ctypes.data_as(i32), 1,
+                                    out.ctypes.data_as(i64)) == EINVAL
+    ok_stride = np.array([12000], np.int32)
+    assert lib.frhot_crop_sharpness(gpu_ctx.handle, ptr, hw.ctypes.data_as(i32), ok_stride.ctypes.data_as(i32),
+                                    gpu_ctx.max_batch + 1, out.ctypes.data_as(i64)) == ECAPACITY
+    assert lib.frhot_crop_sharpness(gpu_ctx.handle, ptr, hw.ctypes.data_as(i32), ok_stride.ctypes.data_as(i32), 1, None) == EINVAL
+    assert b"null" in lib.frhot_last_error()
 
 
 def test_row_sharded_search_dev_merge(gpu_ctx):
