@@ -64,7 +64,7 @@ class ShardedSearch:
             else:
                 self.search_local(q_local, self.s_local, self.r_local, qkeys_local)
             return self.s_local, self.r_local
-        if self.drain:
+        if self.drain and self.q_all.is_cuda:
             torch.cuda.current_stream().synchronize()
         dist.all_gather_into_tensor(self.q_all, q_local)
         if qkeys_local is None:
@@ -72,7 +72,7 @@ class ShardedSearch:
         else:
             dist.all_gather_into_tensor(self.k_all, qkeys_local.to(torch.int32).contiguous())
             self.search_local(self.q_all, self.s_local, self.r_local, self.k_all)
-        if self.drain:
+        if self.drain and self.q_all.is_cuda:
             torch.cuda.current_stream().synchronize()
         # the gather output is passed flat (rank-major): gloo rejects the stacked shape
         dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)

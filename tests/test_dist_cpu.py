@@ -69,7 +69,8 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
             out_s.copy_(torch.from_numpy(np.take_along_axis(cs, order, 1)))
             out_r.copy_(torch.from_numpy(np.take_along_axis(cr, order, 1)))
 
-        ss = ShardedSearch(world, batch, dim, k, torch.device("cpu"), search_local, merge, qdtype=torch.float32)
+        ss = ShardedSearch(world, batch, dim, k, torch.device("cpu"), search_local, merge, qdtype=torch.float32,
+                           drain_before_exchange=(rank == 0))      # no effect on host tensors: must not disturb the exchange
         s, r = ss(torch.from_numpy(q_local), torch.from_numpy(qkeys_local)) if keyed else ss(torch.from_numpy(q_local))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), q=q_local, targets=targets,
                  qkeys=qkeys_local)
