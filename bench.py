@@ -321,7 +321,9 @@ def main():
             gal.search_dev(q_all.data_ptr(), None, q_all.shape[0], K, s_out.data_ptr(), r_out.data_ptr(), row_base)
 
         def merge(s_all, r_all, out_s, out_r):
-            ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), P, P * B, K, out_s.data_ptr(), out_r.data_ptr())
+            # the gathered blocks are merged where the all-gather left them
+            ctx.merge_topk_packed_dev(r_all.data_ptr(), sharded.block_bytes, P, P * B, K, out_s.data_ptr(),
+                                      out_r.data_ptr())
 
         sharded = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse,
                                 drain_before_exchange=share_gpu)

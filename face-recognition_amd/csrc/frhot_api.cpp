@@ -1345,6 +1345,27 @@ int frhot_merge_topk_dev(frhot_ctx* c, const void* scores_dev, const void* rows_
     });
 }
 
+int frhot_merge_topk_packed_dev(frhot_ctx* c, const void* packed_dev, int64_t shard_stride_bytes, int P, int Bq, int k,
+                                void* out_scores_dev, void* out_rows_dev) {
+    return guarded([&]() -> int {
+    if (!c || !packed_dev || !out_scores_dev || !out_rows_dev) return fail(FRHOT_EINVAL, "null argument");
+    if (P <= 0 || P > 256 || Bq <= 0 || k <= 0 || k > 16)
+        return fail(FRHOT_EINVAL, "P %d / Bq %d / k %d out of range (P <= 256, k <= 16)", P, Bq, k);
+    const int64_t n = (int64_t)Bq * k;
+    if (shard_stride_bytes < n * 12 || shard_stride_bytes % 8 || ((uintptr_t)packed_dev & 7u))
+        return fail(FRHOT_EINVAL, "a shard's block holds %lld rows (int64) then %lld scores (float32): the stride must be "
+                    "a multiple of 8 bytes and at least %lld, the buffer 8-byte aligned; got %lld",
+                    (long long)n, (long long)n, (long long)(n * 12), (long long)shard_stride_bytes);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    const char* const b = (const char*)packed_dev;
+    HIP_TRY(launch_topk_final((const float*)(b + n * 8), (const int64_t*)b, P, k, Bq, k, 0, (float*)out_scores_dev,
+                              (int64_t*)out_rows_dev, c->stream, nullptr, nullptr, shard_stride_bytes / 4,
+                              shard_stride_bytes / 8));
+    return FRHOT_OK;
+    });
+}
+
 static int recognise_impl(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* crops, const int32_t* hw,
                           const int32_t* strides, const int32_t* qkeys, int B, unsigned flags, int k, float* emb_out,
                           float* scores, int64_t* rows, int64_t* sharp) {

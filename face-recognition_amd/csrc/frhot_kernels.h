@@ -106,7 +106,9 @@ int scan_list_len(int k);
 hipError_t launch_topk_final(const float* cand_s, const int64_t* cand_r, int nlists, int kin, int Bq, int kout,
                              int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s,
                              const int32_t* out_index = nullptr,      // query i's answer goes to row out_index[i]
-                             const int32_t* nlists_q = nullptr);      // query i merges its first nlists_q[i] lists
+                             const int32_t* nlists_q = nullptr,       // query i merges its first nlists_q[i] lists
+                             int64_t stride_s = 0, int64_t stride_r = 0);   // elements between consecutive lists' blocks
+                                                                            // in cand_s / cand_r (0: Bq * kin, back to back)
 
 // Sets the dynamic-LDS attributes and resolves the static scratch's address on the CURRENT device;
 // call once per device (repeat calls are cheap).

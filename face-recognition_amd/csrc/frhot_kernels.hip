@@ -2197,7 +2197,10 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
                                                         int Bq, int kout, long long row_base,
                                                         float* __restrict__ out_s, long long* __restrict__ out_r,
                                                         const int32_t* __restrict__ out_index,
-                                                        const int32_t* __restrict__ nlists_q) {
+                                                        const int32_t* __restrict__ nlists_q,
+                                                        long stride_s, long stride_r) {
+    // list p of query qi starts at element p * stride + qi * kin of cs / cr: stride = Bq * kin for
+    // lists stored back to back, anything larger for lists that sit inside gathered blocks
     constexpr int NL = 4;                         // lists per lane: nlists <= 256 (checked at launch)
     if (nlists_q) nlists = nlists_q[blockIdx.x];  // this query's own number of lists (may be 0)
     __shared__ float ls[K * 64 * NL];
@@ -2206,12 +2209,13 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < NL; ++t) {
         const int p = lane + 64 * t;
-        const size_t a = ((size_t)(p < nlists ? p : 0) * Bq + qi) * kin;
+        const size_t pl = (size_t)(p < nlists ? p : 0), qa = (size_t)qi * kin;
+        const size_t as = pl * (size_t)stride_s + qa, ar = pl * (size_t)stride_r + qa;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const bool have = p < nlists && j < kin;
-            ls[(j * NL + t) * 64 + lane] = have ? cs[a + j] : -INFINITY;
-            lr[(j * NL + t) * 64 + lane] = have ? cr[a + j] : -1;
+            ls[(j * NL + t) * 64 + lane] = have ? cs[as + j] : -INFINITY;
+            lr[(j * NL + t) * 64 + lane] = have ? cr[ar + j] : -1;
         }
     }
     // heads: (ordered score key, row); an exhausted or empty list has key 0 and the largest row
@@ -2682,20 +2686,27 @@ hipError_t launch_rows_gather_f16(const void* in, const int32_t* index, int n, i
 
 hipError_t launch_topk_final(const float* cs, const int64_t* cr, int nlists, int kin, int Bq, int kout,
                              int64_t row_base, float* out_s, int64_t* out_r, hipStream_t s, const int32_t* out_index,
-                             const int32_t* nlists_q) {
+                             const int32_t* nlists_q, int64_t stride_s, int64_t stride_r) {
     if (nlists <= 0 || nlists > 256 || kin <= 0 || kin > 16 || Bq <= 0 || kout <= 0 || kout > kin || !cs || !cr ||
         !out_s || !out_r)
         return hipErrorInvalidValue;
+    const int64_t dense = (int64_t)Bq * kin;
+    if (stride_s == 0) stride_s = dense;
+    if (stride_r == 0) stride_r = dense;
+    if (stride_s < dense || stride_r < dense) return hipErrorInvalidValue;
     const int kl = scan_klist(kin);
     if (kl == 5)
         hipLaunchKernelGGL((topk_final_kernel<5>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin, Bq,
-                           kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
+                           kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q, (long)stride_s,
+                           (long)stride_r);
     else if (kl == 10)
         hipLaunchKernelGGL((topk_final_kernel<10>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
-                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q, (long)stride_s,
+                           (long)stride_r);
     else
         hipLaunchKernelGGL((topk_final_kernel<16>), dim3(Bq), dim3(64), 0, s, cs, (const long long*)cr, nlists, kin,
-                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q);
+                           Bq, kout, (long long)row_base, out_s, (long long*)out_r, out_index, nlists_q, (long)stride_s,
+                           (long)stride_r);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

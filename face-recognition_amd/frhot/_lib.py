@@ -48,6 +48,7 @@ SIGNATURES = {
     "frhot_search_dev_static": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_search_dev_keyed": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_merge_topk_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "frhot_merge_topk_packed_dev": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, _p, _p]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),
     "frhot_crop_sharpness": (C.c_int, [_p, _u8pp, _i32p, _i32p, C.c_int, _i64p]),

@@ -27,7 +27,10 @@ class ShardedSearch:
                  drain_before_exchange: bool = False):
         """search_local(q_all, scores_out, rows_out[, qkeys_all]): fill [P*B,k] float32 / int64 (global
         rows, -1 = none); the fourth argument (int32 [P*B], same device) is passed only by calls that
-        carry keys.  merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]."""
+        carry keys.  merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]; s_all and r_all are
+        strided views into the gathered blocks (rank p's block starts `block_bytes` after rank
+        p-1's, rows first, then scores: r_all.data_ptr() is the address of the whole buffer), the
+        layout frhot_merge_topk_packed_dev reads."""
         self.P, self.B, self.D, self.k = world, batch, dim, k
         self.search_local, self.merge = search_local, merge
         # always_exchange: run the gathers and the merge even with one rank (a rehearsal of the
@@ -40,16 +43,22 @@ class ShardedSearch:
         self.drain = drain_before_exchange
         n = world * batch
         self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if self.exchange else None
-        # A shard's answer travels as ONE buffer: its rows (int64) followed by its scores (float32),
-        # so a step makes two collectives (queries out, answers back), both latency-bound.
-        self._nr, self._ns = n * k * 8, n * k * 4
-        self.packed = torch.empty(self._nr + self._ns, dtype=torch.uint8, device=device)
-        self.r_local = self.packed[:self._nr].view(torch.int64).view(n, k)
-        self.s_local = self.packed[self._nr:].view(torch.float32).view(n, k)
+        # A shard's answer travels as ONE block: its rows (int64 [n,k]) followed by its scores
+        # (float32 [n,k]), so a step makes two collectives (queries out, answers back), both
+        # latency-bound.  The block is allocated as int64 words (an odd n*k leaves four bytes of
+        # padding at its end), which keeps every view below aligned whatever n and k are.
+        nk = n * k
+        self._words = nk + (nk + 1) // 2
+        self.block_bytes = self._words * 8
+        self.packed = torch.empty(self._words, dtype=torch.int64, device=device)
+        self.r_local = self.packed[:nk].view(n, k)
+        self.s_local = self.packed[nk:].view(torch.float32)[:nk].view(n, k)
         if self.exchange:
-            self.packed_all = torch.empty((world, self._nr + self._ns), dtype=torch.uint8, device=device)
-            self.s_all = torch.empty((world, n, k), dtype=torch.float32, device=device)
-            self.r_all = torch.empty((world, n, k), dtype=torch.int64, device=device)
+            # the gathered blocks, rank-major; the merge reads rows and scores in place through
+            # strided views (stride(0) = one block), no unpacking copies
+            self.packed_all = torch.empty((world, self._words), dtype=torch.int64, device=device)
+            self.r_all = self.packed_all[:, :nk].view(world, n, k)
+            self.s_all = self.packed_all[:, nk:].view(torch.float32)[:, :nk].view(world, n, k)
             self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
             self.out_r = torch.empty((n, k), dtype=torch.int64, device=device)
             self.k_all = torch.empty(n, dtype=torch.int32, device=device)
@@ -76,9 +85,6 @@ class ShardedSearch:
             torch.cuda.current_stream().synchronize()
         # the gather output is passed flat (rank-major): gloo rejects the stacked shape
         dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)
-        # unpack into the two contiguous [P, P*B, k] arrays the merge reads (two small device copies)
-        self.r_all.view(self.P, -1).copy_(self.packed_all[:, :self._nr].view(torch.int64))
-        self.s_all.view(self.P, -1).copy_(self.packed_all[:, self._nr:].view(torch.float32))
         self.merge(self.s_all, self.r_all, self.out_s, self.out_r)
         return self.out_s, self.out_r
 

@@ -150,6 +150,13 @@ class Context:
         check(self._lib.frhot_merge_topk_dev(self._h, C.c_void_p(scores_dev), C.c_void_p(rows_dev), p, bq, k,
                                              C.c_void_p(out_s_dev), C.c_void_p(out_r_dev)))
 
+    def merge_topk_packed_dev(self, packed_dev: int, shard_stride_bytes: int, p: int, bq: int, k: int,
+                              out_s_dev: int, out_r_dev: int):
+        """Merge p shards' answers straight out of an all-gathered buffer: shard i's block at
+        packed_dev + i * shard_stride_bytes = rows int64 [bq,k], then scores float32 [bq,k]."""
+        check(self._lib.frhot_merge_topk_packed_dev(self._h, C.c_void_p(packed_dev), shard_stride_bytes, p, bq, k,
+                                                    C.c_void_p(out_s_dev), C.c_void_p(out_r_dev)))
+
     def recognise(self, gallery: "Gallery", images, qkeys=None, k: int = 5, gamma: bool = False, flip: bool = True,
                   want_embeddings: bool = False, want_sharpness: bool = False):
         """Fused embed -> search.  Returns (scores [n,k], rows [n,k], embeddings or None), and with

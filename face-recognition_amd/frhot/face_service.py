@@ -97,9 +97,10 @@ class FaceService:
 
     def _locate_face(self, data, img_decode, is_detect_face, is_checkin):
         """face_service.py:72-176: the gates on the whole image, detection, the choice of the
-        nearest face and the distance gate.  Returns (True, (x1, y1, x2, y2)), (False, response)
-        or (None, None) where the reference hands back "no embedding" (a detector failure
-        outside check-in, face_service.py:125-126)."""
+        nearest face and the distance gate.  Returns (True, (x1, y1, x2, y2)) or (False, response).
+        A detector failure answers 500 at check-in AND outside it: the reference's other branch
+        (face_service.py:125-126) returns `img_decode` after `del contents, img_decode` (:117), which
+        raises UnboundLocalError into the outer handler (:133-143), i.e. the same 500 body."""
         have = quality.models_installed() if self.quality_gates else {}
         if is_checkin and have.get("face_mesh"):
             ok, message = quality.check_face_left_right(img_decode)
@@ -113,9 +114,7 @@ class FaceService:
                 boxes, _scores, distances = quality.detect_face(img_decode)
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when detecting face: {e}")
-                if is_checkin:
-                    return self._refuse("Error when detecting face! Please try again", 500)
-                return None, None
+                return self._refuse("Error when detecting face! Please try again", 500)
         else:
             boxes, distances = [[0, 0, img_decode.shape[1], img_decode.shape[0]]], [50]   # face_service.py:128-131
         try:
@@ -160,8 +159,6 @@ class FaceService:
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when decoding image: {e}")
                 return self._refuse("Error when detecting face! Please try again", 500)
-            if ok is None:
-                return True, (None, img_decode)
             if not ok:
                 return False, where
             try:
@@ -172,7 +169,10 @@ class FaceService:
                     return False, refused
                 face = adjust_gamma(face, gamma=1.5)                   # face_service.py:223
                 try:
-                    emb, is_real = await loop.run_in_executor(self._pool, lambda: get_embedding(face, img_decode))
+                    # the spoof verdict (legacy.py:60-74) belongs to the gates: one condition for it in
+                    # both paths (see _fused), quality_gates and a registered detector
+                    whole = img_decode if self.quality_gates else None
+                    emb, is_real = await loop.run_in_executor(self._pool, lambda: get_embedding(face, whole))
                     if not is_real and is_checkin:
                         return self._refuse("Face is not real! Please use your real face")
                 except Exception as e:
@@ -196,8 +196,7 @@ class FaceService:
     async def _fused(self, data, collection_name: str, want_embedding: bool, is_checkin: bool = False):
         """decode -> gates -> crop -> ONE device call (gamma LUT + descriptor + search + vote input,
         and the blur measure at check-in).  Returns (False, JSONResponse) with the reference's
-        failure bodies, or (True, (embedding or None, img_decode, search_result)); search_result is
-        None where the reference goes on without an embedding."""
+        failure bodies, or (True, (embedding or None, img_decode, search_result))."""
         if self._fused_sem is None:
             self._fused_sem = asyncio.Semaphore(self._fused_limit)
         loop = asyncio.get_running_loop()
@@ -208,8 +207,6 @@ class FaceService:
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when decoding image: {e}")
                 return self._refuse("Error when detecting face! Please try again", 500)
-            if ok is None:
-                return True, (None, img_decode, None)        # no embedding (face_service.py:125-126)
             if not ok:
                 return False, face
             try:
@@ -224,7 +221,11 @@ class FaceService:
                     refused = self._crop_gates(face, True, sharpness=sharp[0])
                     if refused is not None:
                         return False, refused
-                    if not await loop.run_in_executor(self._pool, face_is_real, img_decode):
+                if self.quality_gates:
+                    # as get_embedding does in the other path: the detector runs on every request (its
+                    # failure answers 500 below), the verdict counts at check-in only (face_service.py:238)
+                    is_real = await loop.run_in_executor(self._pool, face_is_real, img_decode)
+                    if not is_real and is_checkin:
                         return self._refuse("Face is not real! Please use your real face")
             except Exception as e:
                 logger.warning(f"{data.store_id} - Error when encoding face: {e}")

@@ -47,6 +47,10 @@ def face_is_real(imgf_real) -> bool:
     if imgf_real is None or not quality.models_installed()["extract_faces"]:
         return True
     faces = quality._extract_faces(imgf_real)
+    if len(faces) == 0:
+        # DeepFace.extract_faces raises when it finds no face (enforce_detection defaults to True) and
+        # the reference indexes the list unguarded; either way the caller answers 500
+        raise ValueError("Face could not be detected in the whole image")
     best = max(range(len(faces)), key=lambda i: faces[i]['confidence']) if len(faces) > 1 else 0
     return bool(faces[best]["is_real"])
 

@@ -241,6 +241,16 @@ int frhot_merge_topk_dev(frhot_ctx* ctx, const void* scores_dev, const void* row
                          int P, int Bq, int k, void* out_scores_dev, void* out_rows_dev);
 
 /*
+ * The same merge reading the shards' answers where one all-gather leaves them: shard p's block
+ * starts at packed_dev + p * shard_stride_bytes and holds its rows (int64 [Bq,k]) followed by its
+ * scores (float32 [Bq,k]); the stride is a multiple of 8 bytes and at least 12 * Bq * k (blocks may
+ * be padded).  A sharded search exchanges one such block per rank, so the merge needs no unpacking
+ * copies.  Replaces: nothing in the reference (see frhot_merge_topk_dev).
+ */
+int frhot_merge_topk_packed_dev(frhot_ctx* ctx, const void* packed_dev, int64_t shard_stride_bytes,
+                                int P, int Bq, int k, void* out_scores_dev, void* out_rows_dev);
+
+/*
  * Fused embed -> search on one GPU: B host crops, qkeys[B] (or NULL), top-k
  * against gallery g of dimension D (4096, or < 4096 to match on the leading D
  * components re-normalised).  emb_out may be NULL.

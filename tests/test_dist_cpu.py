@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
+def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False, always=False):
     for p in (ROOT, os.path.join(ROOT, "face-recognition_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
 
         keys = (np.arange(n_rows) * 7 % 5).astype(np.int32)         # every rank derives the same keys
         qkeys_local = keys[targets].copy()
-        if rank == 0:
+        if rank == 0 and batch > 2:
             qkeys_local[1] = -2                                       # any collection
             qkeys_local[2] = 77                                       # a collection nobody has
 
@@ -60,6 +60,9 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
             r_out.copy_(torch.from_numpy(r))
 
         def merge(s_all, r_all, out_s, out_r):
+            # strided views into the gathered blocks: rows first, scores behind them, block after block
+            assert s_all.shape[0] == 1 or s_all.stride(0) * 4 == r_all.stride(0) * 8 == ss.block_bytes
+            assert s_all.data_ptr() == r_all.data_ptr() + r_all.shape[1] * r_all.shape[2] * 8
             P, n, kk = s_all.shape
             cs = s_all.permute(1, 0, 2).reshape(n, P * kk).numpy()
             cr = r_all.permute(1, 0, 2).reshape(n, P * kk).numpy()
@@ -70,7 +73,8 @@ def _worker(rank, world, port, n_rows, dim, batch, k, out_dir, keyed=False):
             out_r.copy_(torch.from_numpy(np.take_along_axis(cr, order, 1)))
 
         ss = ShardedSearch(world, batch, dim, k, torch.device("cpu"), search_local, merge, qdtype=torch.float32,
-                           drain_before_exchange=(rank == 0))      # no effect on host tensors: must not disturb the exchange
+                           drain_before_exchange=(rank == 0),      # no effect on host tensors: must not disturb the exchange
+                           always_exchange=always)
         s, r = ss(torch.from_numpy(q_local), torch.from_numpy(qkeys_local)) if keyed else ss(torch.from_numpy(q_local))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), q=q_local, targets=targets,
                  qkeys=qkeys_local)
@@ -102,6 +106,24 @@ def test_sharded_search_equals_global_search(tmp_path, world, n_rows):
         assert (ref_r[1:, 0] == targets[1:]).mean() > 0.8
     else:
         assert (ref_r[:, n_rows:] == -1).all() and (ref_r[:, :n_rows] >= 0).all()
+
+
+@pytest.mark.parametrize("world,batch,k", [(3, 5, 5), (3, 1, 5), (3, 3, 5), (3, 5, 3), (1, 1, 5)])
+def test_sharded_search_odd_entry_counts(tmp_path, world, batch, k):
+    """world * batch * k odd: a rank's block (int64 rows, then float32 scores) no longer ends on an
+    8-byte boundary by itself; the exchange pads it.  World 1 runs the exchange as a rehearsal does."""
+    n_rows, dim = 1000, 64
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_rows, dim, batch, k, str(tmp_path), False, True), nprocs=world, join=True)
+    from frhot import synth
+    from oracle import search as osr
+    g = synth.unit_gallery(seed=123, n=n_rows, d=dim)
+    g[n_rows - 1] = g[0]
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    q_all = np.concatenate([o["q"] for o in outs])
+    ref_s, ref_r = osr.cosine_topk(q_all, g, k)
+    for o in outs:
+        assert np.array_equal(o["r"], ref_r) and np.abs(o["s"] - ref_s).max() < 1e-6
 
 
 @pytest.mark.parametrize("world", [2, 3])

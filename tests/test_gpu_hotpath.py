@@ -792,6 +792,25 @@ def test_row_sharded_search_dev_merge(gpu_ctx):
     full = osr.unit_rows(q).astype(np.float16).astype(np.float32) @ osr.unit_rows(g).astype(np.float16).astype(np.float32).T
     _check_topk(got_s, got_r, ref_s, ref_r, full, tol=2e-5)
     assert list(got_r[0, :2]) == [0, n - 1]
+    # the same lists as ONE all-gather leaves them: per shard a block of rows then scores (37 x 5 is
+    # odd, so a block ends in four bytes of padding), merged in place, must give the same bits
+    nk = bq * k
+    words = nk + (nk + 1) // 2
+    packed = torch.full((P, words), -7, dtype=torch.int64, device=dev)
+    for r in range(P):
+        packed[r, :nk] = lists_r[r].view(-1)
+        packed[r, nk:].view(torch.float32)[:nk] = lists_s[r].view(-1)
+    out_s2 = torch.empty_like(out_s)
+    out_r2 = torch.empty_like(out_r)
+    torch.cuda.synchronize()
+    gpu_ctx.merge_topk_packed_dev(packed.data_ptr(), words * 8, P, bq, k, out_s2.data_ptr(), out_r2.data_ptr())
+    gpu_ctx.sync()
+    assert np.array_equal(out_r2.cpu().numpy(), got_r) and np.array_equal(out_s2.cpu().numpy(), got_s)
+    lib = gpu_ctx._lib
+    import ctypes as C
+    args = (P, bq, k, C.c_void_p(out_s2.data_ptr()), C.c_void_p(out_r2.data_ptr()))
+    assert lib.frhot_merge_topk_packed_dev(gpu_ctx.handle, C.c_void_p(packed.data_ptr()), nk * 12 - 4, *args) == -1
+    assert lib.frhot_merge_topk_packed_dev(gpu_ctx.handle, C.c_void_p(packed.data_ptr()), words * 8 + 4, *args) == -1
     for gal in shards:
         gal.close()
 
@@ -1006,7 +1025,7 @@ def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    n, d, b, k, base = 50_000, 512, 24, 5, 1_000_000
+    n, d, b, k, base = 50_000, 512, 23, 5, 1_000_000        # 23 x 5 entries: an odd count, blocks end in padding
     g = synth.unit_gallery(seed=4, n=n, d=d)
     q = synth.planted_queries(np.random.default_rng(2), g[:b], 0.8)
     gal = Gallery(gpu_ctx, d, n)
@@ -1020,7 +1039,9 @@ def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
             gal.search_dev(q_all.data_ptr(), None, q_all.shape[0], k, s_out.data_ptr(), r_out.data_ptr(), base)
 
         def merge(s_all, r_all, out_s, out_r):
-            gpu_ctx.merge_topk_dev(s_all.data_ptr(), r_all.data_ptr(), 1, b, k, out_s.data_ptr(), out_r.data_ptr())
+            assert s_all.data_ptr() == r_all.data_ptr() + b * k * 8
+            gpu_ctx.merge_topk_packed_dev(r_all.data_ptr(), sharded.block_bytes, 1, b, k, out_s.data_ptr(),
+                                          out_r.data_ptr())
 
         sharded = ShardedSearch(1, b, d, k, dev, search_local, merge, always_exchange=True)
         torch.cuda.synchronize()

@@ -401,7 +401,9 @@ def test_check_in_gates_status_table(mode):
                                    extract_faces=extract)
             # customers are not gated (is_checkin False): the blurred image goes through to the search
             assert recog(blurred, role="0")[0] == 404
-            # enrolment is not gated either, and a detector failure there enrols nothing but answers 200
+            # enrolment is not gated either; a detector failure there (and for customers) answers the same
+            # 500 as at check-in: the reference's "no embedding" branch returns a name it has just
+            # deleted (face_service.py:117,126) and lands in the handler of :133-143
             state.update(mesh=[_mesh(turn=5.0)])
             r = c.post("/create_face_img_base64", headers=H,
                        json={"img_base64": _b64(blurred), "id": "8", "name": "Bob", "role": "1", "store_id": "Q"})
@@ -409,7 +411,20 @@ def test_check_in_gates_status_table(mode):
             state["faces"] = "raise"
             r = c.post("/create_face_img_base64", headers=H,
                        json={"img_base64": _b64(sharp[:100]), "id": "9", "name": "Cy", "role": "1", "store_id": "Q"})
-            assert r.status_code == 200 and r.json() == {"status": 1, "message": "create face Cy with id 9 successfully"}
+            assert r.status_code == 500 and r.json() == {"status": 2, "message": "Error when detecting face! Please try again"}
+            assert recog(sharp, role="0") == (500, {"status": 2, "message": "Error when detecting face! Please try again"})
+            # nothing was stored for id 9
+            state["faces"] = None
+            assert not any(p["payload"]["id"] == "9" for p in svc._points.values())
+            # a detector that finds no face in the whole image during the spoof pass: 500, as the
+            # reference's unguarded face_is_real[0] (legacy.py:74) inside the embedding try block
+            def empty_second_pass(img, calls=[0]):
+                calls[0] += 1
+                return extract(img) if calls[0] % 2 == 1 else []
+            quality.install_models(face_mesh=lambda im: state["mesh"], face_detection=lambda im: state["dets"],
+                                   extract_faces=empty_second_pass)
+            state.update(mesh=[_mesh()])
+            assert recog(sharp) == (500, {"status": 2, "message": "Error! Please try again"})
     finally:
         if recogniser is not None:
             recogniser.close()
