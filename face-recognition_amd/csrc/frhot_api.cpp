@@ -1289,8 +1289,17 @@ int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32
                     "%zu and %zu (8192 queries of top-5, 4096 of top-10, 2048 of top-16)",
                     Bq, k, need, scan_bound_bytes(Bq), sc.entries, sc.bound_bytes);
     if (g->nrows == 0) return search_fill_empty(c->stream, Bq, k, (float*)scores_dev, (int64_t*)rows_dev);
-    return search_launch(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base, sc.part_s,
-                         sc.part_r, sc.qbound);
+    // every context and stream on this GPU shares the one array: a second context gets it only once
+    // the work of the one before has completed
+    const hipError_t ec = scan_static_claim(c->device, c);
+    if (ec == hipErrorNotReady)
+        return fail(FRHOT_ESTATE, "the static scratch of GPU %d is in use by another context whose search has not "
+                    "finished; wait for it (frhot_ctx_sync) or use frhot_search_dev", c->device);
+    HIP_TRY(ec);
+    const int rc = search_launch(g, q_f16_dev, qkeys_dev, Bq, k, (float*)scores_dev, (int64_t*)rows_dev, row_base,
+                                 sc.part_s, sc.part_r, sc.qbound);
+    HIP_TRY(scan_static_mark(c->device, c, c->stream));
+    return rc;
     });
 }
 

@@ -100,6 +100,12 @@ struct ScanStaticScratch {
     size_t bound_bytes;   // bytes behind qbound
 };
 hipError_t scan_static_scratch(int device, ScanStaticScratch* out);
+// One user of a GPU's static scratch at a time.  claim: `owner` (any stable address, e.g. the
+// calling context) takes the array over; hipErrorNotReady while work another owner marked is still
+// running on that GPU.  mark: record, on the stream the owner just enqueued on, the point after
+// which the array is free again.  Neither allocates.
+hipError_t scan_static_claim(int device, const void* owner);
+hipError_t scan_static_mark(int device, const void* owner, hipStream_t s);
 // Length of the per-block candidate lists the scan writes for a request of k (5, 10 or 16).
 int scan_list_len(int k);
 // Final selection over nlists lists of kin (layout [nlists][Bq][kin]) -> best kout per query.

@@ -2535,6 +2535,10 @@ static __device__ __align__(256) unsigned char scratch[kScanStaticBytes];
 
 constexpr int kMaxDevices = 64;
 static void* g_scratch_ptr[kMaxDevices];          // device address of `scratch` on each GPU (0: not resolved yet)
+// Who used a GPU's array last, and an event behind that use: another owner may take the array over
+// only once the event has completed (two owners' kernels would otherwise overlap on it).
+static const void* g_scratch_owner[kMaxDevices];
+static hipEvent_t g_scratch_done[kMaxDevices];
 static std::mutex g_scratch_mu;
 
 // Resolves the address of `scratch` on the CURRENT device (once per device).
@@ -2549,8 +2553,32 @@ static hipError_t scan_static_resolve() {
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!p || ((uintptr_t)p & 255u)) return hipErrorInvalidSymbol;
+    e = hipEventCreateWithFlags(&g_scratch_done[dev], hipEventDisableTiming);
+    if (e != hipSuccess) return e;
     g_scratch_ptr[dev] = p;
     return hipSuccess;
+}
+
+hipError_t scan_static_claim(int device, const void* owner) {
+    if (device < 0 || device >= kMaxDevices || !owner) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) return hipErrorNotInitialized;
+    if (g_scratch_owner[device] && g_scratch_owner[device] != owner) {
+        const hipError_t e = hipEventQuery(g_scratch_done[device]);
+        if (e != hipSuccess) {                    // hipErrorNotReady: the other owner's work is still running
+            (void)hipGetLastError();              // (not an error of a later launch on this thread)
+            return e;
+        }
+    }
+    g_scratch_owner[device] = owner;
+    return hipSuccess;
+}
+
+hipError_t scan_static_mark(int device, const void* owner, hipStream_t s) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_owner[device] != owner) return hipErrorInvalidValue;
+    return hipEventRecord(g_scratch_done[device], s);
 }
 
 hipError_t scan_static_scratch(int device, ScanStaticScratch* out) {

@@ -223,8 +223,11 @@ int frhot_search_dev_keyed(frhot_gallery* g, const void* q_f16_dev, const int32_
  * the call makes no hipMalloc / hipFree / allocating library call.  Limits: walkers x queries x
  * list length <= 327,680 entries and at most 8192 queries, i.e. up to 8192 queries of top-5,
  * 4096 of top-10, 2048 of top-16; beyond that FRHOT_ECAPACITY.  All calls on one GPU share
- * that GPU's array: calls that overlap on one GPU (two contexts, two streams) race; calls on
- * one context are serialised by its stream as usual.
+ * that GPU's array.  Calls on one context are serialised by its stream as usual; a call from
+ * ANOTHER context of the process on the same GPU while the previous context's search is still
+ * running is refused with FRHOT_ESTATE (its kernels would overlap on the array).  Not detected:
+ * two processes never share the array (each loads its own copy), and a caller that runs one
+ * context's work on several streams of its own must order them itself.
  */
 int frhot_search_dev_static(frhot_gallery* g, const void* q_f16_dev, const int32_t* qkeys_dev,
                             int Bq, int k, void* scores_dev, void* rows_dev, int64_t row_base);

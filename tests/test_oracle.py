@@ -98,6 +98,27 @@ def test_resize_agrees_with_an_independent_bilinear():
         assert np.abs(got - ref).max() <= 1.0, (h, w, dh, dw, np.abs(got - ref).max())
 
 
+def test_edge_geometries_agree_with_an_independent_bilinear():
+    """The crop geometries the GPU parity test walks (tests/test_gpu_hotpath.py::_crops: square, wide,
+    tall, one pixel, one row, almost-2x, almost-identity, more than 6x down, ...) through deepface's
+    aspect fit, against torch's bilinear interpolation: within one grey level everywhere.  The exact
+    2x reduction (448 x 448) is the documented exception: cv2 averages 2 x 2 boxes there, and the
+    box average equals bilinear taps at weight 1/2 each, so it too stays within one level."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    shapes = [(96, 300), (300, 96), (171, 204), (257, 113), (299, 298), (448, 448), (224, 224), (130, 517), (601, 97),
+              (64, 80), (50, 50), (1, 1), (2, 3), (3, 500), (447, 449), (225, 223), (1500, 1400), (300, 200)]
+    assert len(shapes) == 18
+    for h, w in shapes:
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        dw, dh = op.fit_size(h, w)
+        got = op.resize_linear_u8(img, dw, dh).astype(np.float64)
+        t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+        ref = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1.0, (h, w, dh, dw, np.abs(got - ref).max())
+
+
 def test_pad_is_centred_and_becomes_minus_mean():
     img = np.full((100, 50, 3), 200, np.uint8)
     u8 = op.resize_pad_u8(img)

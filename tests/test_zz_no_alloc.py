@@ -76,3 +76,88 @@ def test_static_scratch_search_equals_search_dev(gpu_ctx):
     with pytest.raises(FrhotError):
         gal.search_dev_static(big.data_ptr(), None, 4100, 10, s.data_ptr(), r.data_ptr(), 0)
     gal.close()
+
+
+def _free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def test_static_search_allocates_no_device_memory(gpu_ctx):
+    """The property the entry point exists for: free device memory does not move across
+    frhot_search_dev_static calls, each larger than any call before it on a gallery that never ran
+    frhot_search_dev, while the same sequence through frhot_search_dev does take memory (its
+    candidate lists and bounds grow on demand)."""
+    import torch
+    from frhot.engine import Gallery
+    dev = torch.device("cuda", 0)
+    n, d = 300_000, 64
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=5, row0=0, n=n, nkeys=0, dup_every=0)
+    sizes = [(300, 5), (1000, 10), (2048, 16), (8192, 5)]
+    bqmax = max(b for b, _ in sizes)
+    q = torch.randn((bqmax, d), device=dev).to(torch.float16)
+    s = torch.empty((bqmax, 16), dtype=torch.float32, device=dev)
+    r = torch.empty((bqmax, 16), dtype=torch.int64, device=dev)
+    # every kernel instantiation once, at small sizes: whatever the runtime sets up lazily at a
+    # kernel's first launch is not this entry point's doing
+    for bq, k in [(1, 5), (1, 10), (1, 16), (100, 5), (100, 10), (200, 5)]:
+        gal.search_dev_static(q.data_ptr(), None, bq, k, s.data_ptr(), r.data_ptr(), 0)
+    gpu_ctx.sync()
+    before = _free_bytes()
+    for bq, k in sizes:
+        gal.search_dev_static(q.data_ptr(), None, bq, k, s.data_ptr(), r.data_ptr(), 0)
+        gpu_ctx.sync()
+        assert _free_bytes() == before, f"static search of {bq} queries, top-{k}, changed free device memory"
+    want_r = r.view(-1)[:8192 * 5].clone()          # the last static answer (8192 queries of top-5)
+    for bq, k in sizes:
+        gal.search_dev(q.data_ptr(), None, bq, k, s.data_ptr(), r.data_ptr(), 0)
+    gpu_ctx.sync()
+    after = _free_bytes()
+    assert after < before - 50 * 8192 * 5, "frhot_search_dev was expected to allocate its candidate lists"
+    assert torch.equal(want_r, r.view(-1)[:8192 * 5])
+    gal.close()
+
+
+def test_static_scratch_is_refused_to_a_second_context_while_busy(gpu_ctx):
+    """One array per GPU: a second context's call while the first context's searches are still
+    running gets FRHOT_ESTATE instead of the array; once the first has finished it gets it."""
+    import torch
+    from frhot import FrhotError
+    from frhot.engine import Context, Gallery
+    dev = torch.device("cuda", 0)
+    n, d, bq = 2_000_000, 64, 512
+    gal = Gallery(gpu_ctx, d, n)
+    gal.fill_synthetic(seed=6, row0=0, n=n, nkeys=0, dup_every=0)
+    other = Context(device=0, max_batch=1)
+    small = Gallery(other, d, 1000)
+    small.fill_synthetic(seed=7, row0=0, n=1000, nkeys=0, dup_every=0)
+    q = torch.randn((bq, d), device=dev).to(torch.float16)
+    s = torch.empty((bq, 5), dtype=torch.float32, device=dev)
+    r = torch.empty((bq, 5), dtype=torch.int64, device=dev)
+    s2 = torch.empty((4, 5), dtype=torch.float32, device=dev)
+    r2 = torch.empty((4, 5), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    try:
+        for _ in range(200):                 # about 0.2 ms each: tens of milliseconds of queued work
+            gal.search_dev_static(q.data_ptr(), None, bq, 5, s.data_ptr(), r.data_ptr(), 0)
+        with pytest.raises(FrhotError) as e:
+            small.search_dev_static(q.data_ptr(), None, 4, 5, s2.data_ptr(), r2.data_ptr(), 0)
+        assert e.value.code == -3 and "in use" in e.value.message
+        gpu_ctx.sync()
+        small.search_dev_static(q.data_ptr(), None, 4, 5, s2.data_ptr(), r2.data_ptr(), 0)   # now it is free
+        other.sync()
+        want_s = torch.empty_like(s2)
+        want_r = torch.empty_like(r2)
+        small.search_dev(q.data_ptr(), None, 4, 5, want_s.data_ptr(), want_r.data_ptr(), 0)
+        other.sync()
+        assert torch.equal(r2, want_r) and torch.equal(s2, want_s)
+        # and back: the first context takes it over again once the second is idle
+        gal.search_dev_static(q.data_ptr(), None, bq, 5, s.data_ptr(), r.data_ptr(), 0)
+        gpu_ctx.sync()
+    finally:
+        gpu_ctx.sync()
+        small.close()
+        other.close()
+        gal.close()
