@@ -512,6 +512,7 @@ int search_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys_dev, 
         HIP_TRY(free_null(g->qbound));
         const size_t cap = scan_bound_bytes(Bq + Bq / 2);
         HIP_TRY(hipMalloc((void**)&g->qbound, cap));
+        HIP_TRY(hipMemset(g->qbound, 0, cap));         // slots start out empty; no launch clears them again
         g->qbound_cap = cap;
     }
     return search_launch(g, q16, qkeys_dev, Bq, k, scores_dev, rows_dev, row_base, g->part_s, g->part_r, g->qbound);
@@ -633,7 +634,7 @@ int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys
         if (ntl == 0) continue;
         const int nb = (int)std::min<int64_t>(ntl, budget);
         if (nb > max_nb) max_nb = nb;
-        if (ntl / nb >= 24) long_walks = true;
+        if (ntl / nb >= 3) long_walks = true;          // (enough tiles for the bounds to come round)
         for (int i = 0; i < gr.qn; ++i) nlists[(size_t)(gr.qbeg + i)] = nb;
         for (int q0 = gr.qbeg; q0 < gr.qbeg + gr.qn; q0 += 64)
             for (int gb = 0; gb < nb; ++gb)
@@ -691,6 +692,7 @@ int search_keyed_enqueue(frhot_gallery* g, const void* q16, const int32_t* qkeys
         HIP_TRY(free_null(g->qbound));
         const size_t cap = scan_bound_bytes(Bq + Bq / 2 + 64);
         HIP_TRY(hipMalloc((void**)&g->qbound, cap));
+        HIP_TRY(hipMemset(g->qbound, 0, cap));
         g->qbound_cap = cap;
     }
     int32_t* const h = pin.p;

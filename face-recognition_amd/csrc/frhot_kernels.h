@@ -67,8 +67,11 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* q_f16, int Bq, int D, hi
 // Scan: per-block partial top-k lists into part_s/part_r ([nblk][Bq][k]); returns nblk via *nblk_out.
 int scan_max_blocks();
 // g_f16 / g_keys must be allocated in whole tiles of 256 rows (reads run to the tile end).
-// qbound: scan_bound_bytes(Bq) bytes of device scratch (cross-block score bounds), or null.
+// qbound: scan_bound_bytes(Bq) bytes of device scratch (cross-block score bounds), or null.  The
+// scratch must be ZEROED once when it is allocated: the 64-query kernel never clears it (its slots
+// carry the number of the launch that wrote them), the wider kernels clear it on the stream themselves.
 size_t scan_bound_bytes(int Bq);
+void scan_set_sel_variant(int v);          // 64-query tile: 0 = the kernel without the selector wave (micro-benchmark A/B), 1 = with
 void scan_set_bound_min_tiles(int tiles);   // blocks that walk fewer tiles scan without the bounds (< 0: built-in rule)
 hipError_t launch_scan_topk(const void* g_f16, const int32_t* g_keys, int64_t nrows, int D,
                             const void* q_f16, const int32_t* qkeys, int use_keys, int Bq, int k,

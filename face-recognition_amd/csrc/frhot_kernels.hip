@@ -14,6 +14,8 @@
 // ds_read_b128, v_mfma_f32_16x16x32_f16 accumulation in fp32.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "frhot_kernels.h"
@@ -31,6 +33,7 @@ namespace frhot {
 // scan diagnosis, per block (wave 0): {entry, loop begin, loop end, exit, cycles inside tile ends, tile ends,
 // insertion rounds, cycles before the per-group work, in the per-group preludes, in the insertion loops}
 __device__ unsigned long long g_scan_stamp[256 * 16];
+__device__ unsigned long long g_scan_tiles[256 * 20];     // wave 0: clock at the end of each of the first 20 tiles
 #endif
 #if FR_DBG & (8 | 32 | 64)
 __device__ unsigned long long g_stamp[64];
@@ -2171,6 +2174,678 @@ __global__ __launch_bounds__(512) void scan_topk_kernel(const half_t* __restrict
 #endif
 }
 
+// ------------------------------------- 64-query scan with a selector wave ---
+// LDS accesses of the selection queues, written as the instructions themselves (see lds_offset).
+FR_DEV unsigned lds_read_u32(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+FR_DEV unsigned long long lds_read_u64(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+FR_DEV void lds_write_u32(unsigned addr, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+FR_DEV void lds_write_u64(unsigned addr, unsigned long long v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// 16 consecutive words at addr (64-byte aligned)
+FR_DEV void lds_read_16u32(unsigned addr, unsigned (&o)[16]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 v0, v1, v2, v3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(addr) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = v0[j]; o[4 + j] = v1[j]; o[8 + j] = v2[j]; o[12 + j] = v3[j]; }
+}
+// four 8-byte words at addr, addr + stride, ... (stride in bytes, a compile-time constant below 16 KiB)
+FR_DEV void lds_read_4u64(unsigned addr, int stride, unsigned long long (&o)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b64 %2, %4 offset:%6\n\t"
+                 "ds_read_b64 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                 : "v"(addr), "n"(512), "n"(1024), "n"(1536)
+                 : "memory");
+    (void)stride;
+}
+// two words, 64 bytes apart (the thresholds of a lane's two query columns), one wait
+FR_DEV void lds_read_2u32_64(unsigned addr, unsigned& a, unsigned& b) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+}
+FR_DEV unsigned lds_add_rtn_u32(unsigned addr, unsigned v) {
+    unsigned r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+
+// The 64-query tile of the gallery scan (HBM-bound: 64 flop per gallery byte) with the top-k
+// selection taken off the streaming waves.  576 threads: waves 0..7 stream the gallery exactly
+// as scan_topk_kernel<K, 64, 4, 2> does (256-row tiles through an LDS-DMA ring, MFMA against
+// the 64 queries), wave 8 is the SELECTOR: lane l keeps THE sorted top-K list of query l of
+// the tile for everything this block scans, in registers.
+//   * thr[64] in LDS is a lower bound on each query's K-th best score (the selector's list
+//     tail once the list is full, raised by the cross-block bound when there is one), as an
+//     ordered key, only ever raised (LDS atomic max).
+//   * At a tile end the streaming waves only FILTER: one three-input max per two scores and a
+//     ballot; a lane with scores >= thr reserves as many consecutive entries of its query's
+//     queue in LDS as it has survivors (one LDS atomic add) and writes them, 8 bytes each:
+//     {ordered key of the score, ~row}.  Two queues, by tile parity.
+//   * The selector drains the queue of tile t into its lists while the streaming waves run the
+//     steps of tile t+1 (a few entries per step, between the same barriers; insertion without
+//     a branch), publishes the new thr, and, when the launch has cross-block bounds, exchanges
+//     them through device memory: its loads and stores wait in nobody's memory queue but its own.
+//   * A block's first tile has no threshold yet, and every block of the launch is at its first
+//     tile at the same time, so nothing there may be serial.  The 16 lists of a query (4 lanes
+//     x 4 waves) put their best score into a table; the largest of them that at least K reach
+//     is a first threshold (K rows score at least that); the survivors are queued as usual and
+//     then RANKED by the streaming waves, eight lanes per query (rank = number of the query's
+//     entries with a larger key), which leaves every query's start list in order in LDS for
+//     the selector to pick up.
+//   * A full queue (more than CAP survivors of one query in one tile: ties, adversarial
+//     orders) is exact too: lanes that found no room raise a flag, every wave sees it after the
+//     barrier, the selector drains at once, and the lanes try again with the new thresholds.
+// Every wave executes the same sequence of barriers: the counts (tile ends, the first tile's
+// extra ones, two per overflow round) derive from values all nine waves read from LDS
+// after a barrier and before anyone writes them again.
+// The block's lists come out sorted (score descending, row ascending among equal scores)
+// straight from the selector's registers: there is no merge at the end.
+// Measured on 1 M x 512 x 64 queries, top-10 (one MI355X, same box, queries and merge as the
+// benchmark runs them): 0.205 -> 0.173 ms (0.74 of 8 TB/s); 1 M x 4096 x 64: 1.185 -> 1.165 ms.
+template <int K, bool USE_KEYS, bool WORK, int XS, int YS, int CAP>
+__global__ __launch_bounds__(576) void scan_sel_kernel(const half_t* __restrict__ gal,
+                                                          const int32_t* __restrict__ gkeys, long nrows, int D,
+                                                          const half_t* __restrict__ q,
+                                                          const int32_t* __restrict__ qkeys, int Bq, int nb,
+                                                          float* __restrict__ part_s, long long* __restrict__ part_r,
+                                                          unsigned* __restrict__ qbound,
+                                                          const int32_t* __restrict__ tile_list, long ntl,
+                                                          const ScanWork* __restrict__ work, unsigned long long gen) {
+    constexpr int RY = 64, WY = 2, TX = 64, TY = 32, NX = 4, NY = 2;
+    constexpr int XB = 256 * 128, YB = RY * 128;
+    constexpr int DX = XS - 1, DY = YS - 1, NPX = 4, NPY = 1;
+    // loads that may stay in flight at the end of a step: those issued after the later of
+    // gallery step s+1 and query slice s+1
+    constexpr int IFX = (DX - 1) * (NPX + NPY), IFY = NPX + (DY - 1) * (NPX + NPY);
+    constexpr int INFLIGHT = IFX < IFY ? IFX : IFY;
+    static_assert(XS >= 3 && YS >= 2 && CAP >= K, "ring depths / queue length");
+    constexpr int CTRL = XS * XB + YS * YB;         // thr[64] | cnt[2][64] | overflow tag
+    constexpr int QUEUE = CTRL + 1024;              // [2][CAP][64] entries of 8 bytes
+    constexpr unsigned LOWEST_KEY = 0x00800000u;    // ordered key of -FLT_MAX: below every score, above the struck-out -inf
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs = smem;
+    char* const ys = smem + XS * XB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = (wave & 7) / WY, wy = wave % WY;
+    const int l15 = lane & 15, g0 = lane >> 4, l7 = lane & 7;
+    const unsigned a_thr = lds_offset(smem + CTRL), a_cnt = a_thr + 256, a_ovf = a_thr + 768;
+    const unsigned a_queue = lds_offset(smem + QUEUE);
+    // first tile only, in the second queue's memory (unused until the second tile's end):
+    const unsigned a_boot = a_queue + CAP * 512;    // [64 queries][16 lists] best score of every list (ordered keys)
+    const unsigned a_init = a_boot + 4096;          // [64 queries][K] start lists
+    static_assert(4096 + 64 * K * 8 <= CAP * 512 && CAP % 8 == 0 && CAP <= 32, "first-tile tables");
+
+    int qtiles, q0, gb, bql = Bq;       // bql: queries at and past this one are not this block's
+    if (WORK) {
+        const ScanWork w = work[blockIdx.x];
+        q0 = w.q0; bql = w.qend; gb = w.gb; nb = w.nb; ntl = w.ntl;
+        tile_list = w.tile_off >= 0 ? tile_list + w.tile_off : nullptr;
+        qtiles = 2;                     // other blocks may read the same tiles: keep them in L2
+    } else {
+        qtiles = gridDim.x / nb;
+        const int L = blockIdx.x, xcd = L & 7, seq = L >> 3;
+        gb = (seq / qtiles) * 8 + xcd;
+        q0 = (seq % qtiles) * RY;
+    }
+    const int nk = D / 64;
+    const long ntiles = (WORK && tile_list) ? ntl : (nrows + 255) / 256;
+    const long my_tiles = gb < ntiles ? (ntiles - gb + nb - 1) / nb : 0;
+    const long S = my_tiles * nk;
+
+    if (wave == 8) {
+        // ------------------------------------------------------------ selector
+        // The list is kept as K 64-bit keys, best first: {ordered key of the score, ~row}, so one
+        // unsigned comparison orders by score and, among equal scores, by ascending row; 0 = empty.
+        __builtin_amdgcn_s_setprio(3);              // short bursts of work that the streaming waves wait for
+        unsigned long long key[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) key[j] = 0ull;
+        const unsigned ql = (unsigned)lane;
+#if FR_DBG & 64
+        unsigned long long sl_a = 0, sl_b = 0, sl_drain = 0, sl_rounds = 0;
+#endif
+        if (S > 0) {
+            lds_write_u32(a_thr + ql * 4, LOWEST_KEY);
+            lds_write_u32(a_cnt + ql * 4, 0u);
+            lds_write_u32(a_cnt + 256 + ql * 4, 0u);
+            if (lane == 0) lds_write_u32(a_ovf, 0u);
+#pragma unroll
+            for (int j = 0; j < K; ++j) lds_write_u64(a_init + (ql * K + (unsigned)j) * 8, 0ull);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // the streaming waves' prologue barrier
+            int pend = -1;                          // queue being drained beside the next tile's steps
+            unsigned n = 0, i = 0;                  // this lane's entries in it; the round (same in every lane)
+            unsigned chk = 0, tdone = 0;
+            int ks = 0;
+            unsigned bound = LOWEST_KEY;            // cross-block bound of this lane's query (ordered key)
+            bool xpending = false;                  // the slots were asked for during the previous interval
+            unsigned long long xv[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) xv[j] = 0ull;
+            unsigned long long* const slots = (unsigned long long*)qbound + (size_t)(q0 + (int)ql) * K;
+            const int qq = q0 + (int)ql;
+            const unsigned myslot = (unsigned)gb % (unsigned)K;
+            const unsigned myturn = (unsigned)gb / (unsigned)K, nclass = ((unsigned)nb + K - 1) / (unsigned)K;
+            // the slots are asked for early in a tile and used at its last step but one (short tiles: at
+            // the next tile's first step, before asking again)
+            const int xask = nk >= 4 ? 1 : 0, xuse = nk >= 4 ? nk - 2 : 0;
+#ifdef FR_SEL_R
+            const int R = FR_SEL_R;
+#else
+            const int R = (CAP + nk - 1) / nk > 4 ? (CAP + nk - 1) / nk : 4;
+#endif
+            // One entry of every lane's queue: branch-free insertion.  b[j]: the entry beats list
+            // place j (then it beats every later place too); place j takes the entry, its left
+            // neighbour, or keeps its own.  Lanes without an entry insert key 0, which beats nothing.
+            auto drain_round = [&](unsigned p) __attribute__((always_inline)) {
+#if FR_DBG & 64
+                ++sl_rounds;
+#endif
+                const unsigned long long e = lds_read_u64(a_queue + ((p * CAP + i) * 64 + ql) * 8);
+                const unsigned long long nkey = i < n ? e : 0ull;
+                bool b[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) b[j] = nkey > key[j];
+#pragma unroll
+                for (int j = K - 1; j > 0; --j) {
+                    const unsigned long long left = b[j - 1] ? key[j - 1] : nkey;
+                    key[j] = b[j] ? left : key[j];
+                }
+                key[0] = b[0] ? nkey : key[0];
+                ++i;
+            };
+            auto publish = [&]() __attribute__((always_inline)) {
+                const unsigned tail = (unsigned)(key[K - 1] >> 32);         // 0 while the list is not full
+                lds_max_u32(a_thr + ql * 4, tail > bound ? tail : bound);
+            };
+            auto queued = [&](unsigned p) __attribute__((always_inline)) {
+                const unsigned c = lds_read_u32(a_cnt + p * 256 + ql * 4);
+                return c < (unsigned)CAP ? c : (unsigned)CAP;
+            };
+            for (long s = 0; s < S; ++s) {
+                const bool tile_end = ks == nk - 1;
+                if (xpending && (ks == xuse)) {
+                    // Cross-block bound: K slots per query in device memory; slot j belongs to the blocks
+                    // with (block mod K) = j, which scan rows no other class scans, and holds a score that
+                    // some row of the class reached for the query: K different rows score at least the
+                    // slots' minimum.  A slot is {launch number: 40 bits, leading 24 bits of the score's
+                    // ordered key}: what earlier launches left behind reads as empty, so nothing clears the
+                    // slots, and a key cut short is a lower score, which keeps the bound a bound.
+                    // The blocks of a class take TURNS at writing their slot (one per tile: block c of the
+                    // class after tile c, c + classes, ...), with a plain write-through store of the larger
+                    // of what the slot held and the block's own best.  No atomics: 256 blocks raising the
+                    // same few lines at once held the whole chip's stream up for tens of microseconds.  Two
+                    // blocks out of step may write one slot at once and one value is lost: whatever is left
+                    // is still a score a row of the class reached.
+                    unsigned m = 0xffffffffu, mine = 0u;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const unsigned kj = (xv[j] >> 24) == gen ? (unsigned)(xv[j] & 0xffffffu) : 0u;
+                        m = kj < m ? kj : m;
+                        mine = (unsigned)j == myslot ? kj : mine;
+                    }
+                    const unsigned hk = (unsigned)(key[0] >> 40);       // 0: no row yet
+                    // (work-list form: columns past the key's last query belong to other keys' queries)
+                    if ((!WORK || qq < bql) && tdone % nclass == myturn && hk > mine)
+                        __hip_atomic_store(slots + myslot, (gen << 24) | (unsigned long long)hk, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    m <<= 8;
+                    bound = m > bound ? m : bound;
+                    publish();
+                    xpending = false;
+                }
+                if (pend >= 0) {
+                    int rounds = tile_end ? CAP : R;        // a tile's last step completes the drain
+#if FR_DBG & 64
+                    FR_STAMP(sl_a);
+#endif
+                    while (rounds-- > 0 && __any(i < n)) drain_round((unsigned)pend);
+#if FR_DBG & 64
+                    FR_STAMP(sl_b);
+                    sl_drain += sl_b - sl_a;
+#endif
+                    if (!__any(i < n)) {
+                        lds_write_u32(a_cnt + (unsigned)pend * 256 + ql * 4, 0u);
+                        publish();
+                        pend = -1;
+                    }
+                }
+                // Under a full-rate gallery stream a load takes microseconds to come back, and the wait
+                // for it stands in front of a barrier every streaming wave waits at: hence the distance
+                // between asking and using.
+                if (qbound != nullptr && ks == xask && tdone > 0) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        xv[j] = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xpending = true;
+                }
+                if (tile_end) {
+                    const unsigned p = tdone & 1u;
+                    if (tdone == 0 && !(FR_DBG & 128)) {    // the streaming waves work out the first thresholds
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    for (;;) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();       // A: this round's entries are in the queue
+                        ++chk;
+                        const bool again = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_read_u32(a_ovf)) == chk;
+                        if (!again) break;
+                        n = queued(p); i = 0;
+#if FR_DBG & 64
+                        FR_STAMP(sl_a);
+#endif
+                        while (__any(i < n)) drain_round(p);
+#if FR_DBG & 64
+                        FR_STAMP(sl_b);
+                        sl_drain += sl_b - sl_a;
+#endif
+                        lds_write_u32(a_cnt + p * 256 + ql * 4, 0u);
+                        publish();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();       // B: thresholds are out, the queue is empty
+                    }
+                    if (tdone == 0 && !(FR_DBG & 128) && chk == 1) {
+                        // First tile without an overflow: the streaming waves have ranked its queue (see
+                        // there) and left every query's best K entries, in order, in the start-list table.
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+#pragma unroll
+                        for (int j = 0; j < K; ++j) key[j] = lds_read_u64(a_init + (ql * K + (unsigned)j) * 8);
+                        lds_write_u32(a_cnt + ql * 4, 0u);
+                        publish();
+                        // the first block of every class writes its best to the class's slot at once: the
+                        // others read it early in the second tile
+                        const unsigned hk = (unsigned)(key[0] >> 40);
+                        if (qbound != nullptr && (!WORK || qq < bql) && myturn == 0 && hk != 0u)
+                            __hip_atomic_store(slots + myslot, (gen << 24) | (unsigned long long)hk, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        n = 0; i = 0; pend = -1;
+                    } else {
+                        n = queued(p); i = 0; pend = (int)p;
+                    }
+                    ++tdone; ks = 0;
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    ++ks;
+                }
+            }
+            if (pend >= 0)
+                while (__any(i < n)) drain_round((unsigned)pend);
+        }
+        if (q0 + (int)ql < bql) {
+            const size_t o = ((size_t)gb * Bq + q0 + ql) * K;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const unsigned h = (unsigned)(key[j] >> 32);
+                part_s[o + j] = h ? ordered_value(h) : -INFINITY;
+                part_r[o + j] = h ? (long long)(~(unsigned)key[j]) : -1;
+            }
+        }
+#if FR_DBG & 64
+        FR_STAMP(sl_a);
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned long long* const o = g_scan_stamp + blockIdx.x * 16;
+            o[3] = sl_a; o[6] = sl_rounds; o[9] = sl_drain;
+        }
+#endif
+        return;
+    }
+
+    // ------------------------------------------------------------ streaming waves
+    if (S <= 0) return;
+#if FR_DBG & 64
+    unsigned long long sc_t0 = 0, sc_t1 = 0, sc_t2 = 0, sc_ta = 0, sc_tb = 0, sc_sel = 0, sc_n = 0, sc_boot = 0, sc_ovr = 0;
+    FR_STAMP(sc_t0);
+#endif
+    const int cb = ((l7 ^ (lane >> 3)) << 4);
+    const unsigned xo0 = (unsigned)((8 * wave + (lane >> 3)) * D * 2 + cb);
+    const unsigned xg0 = (unsigned)((8 * wave + (lane >> 3)) * 128 + cb);
+    const unsigned yq0 = (unsigned)q0 * (unsigned)D * 2u;
+    const unsigned yomax = (unsigned)(bql - 1) * (unsigned)D * 2u + (unsigned)cb;
+    float4v acc[NY][NX];
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+        for (int x = 0; x < NX; ++x) acc[y][x] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    long itile = gb; int iks = 0;   // next gallery step to issue
+    int yks = 0;                    // next query slice to issue
+    auto issue_x = [&](int slot) __attribute__((always_inline)) {
+        const long ptile = (WORK && tile_list) ? (long)tile_list[__builtin_amdgcn_readfirstlane((int)itile)] : itile;
+        const char* const base = (const char*)gal + ((size_t)ptile * nk + (size_t)iks) * 32768;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            unsigned o = xg0;
+            asm volatile("" : "+v"(o));
+            if (qtiles == 1) glds16_nt(base + (size_t)i * 8192 + o, xs + slot * XB + (wave + 8 * i) * 1024);
+            else glds16(base + (size_t)i * 8192 + o, xs + slot * XB + (wave + 8 * i) * 1024);
+        }
+        if (++iks == nk) { iks = 0; itile += nb; }
+    };
+    auto issue_y = [&](int slot) __attribute__((always_inline)) {
+        unsigned o = xo0;
+        asm volatile("" : "+v"(o));
+        o += yq0;
+        o = o < yomax ? o : yomax;
+        glds16((const char*)q + (size_t)yks * 128 + o, ys + slot * YB + wave * 1024);
+        if (++yks == nk) yks = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < DY; ++i)
+        if (i < S) issue_y(i);
+#pragma unroll
+    for (int i = 0; i < DX; ++i)
+        if (i < S) issue_x(i);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if FR_DBG & 64
+    FR_STAMP(sc_t1);
+#endif
+
+    half8 fx[NX], fy[NY];
+    int xslot = 0, yslot = 0, ks = 0;
+    long tile = gb;
+    unsigned tdone = 0, chk = 0;
+    const unsigned qa = (unsigned)((wy * TY + l15) * 4);     // byte offset of query (y = 0) in thr / cnt
+    for (long s = 0; s < S; ++s) {
+        const char* const xbuf = xs + xslot * XB;
+        const char* const ybuf = ys + yslot * YB;
+        auto unit = [&](auto uc) __attribute__((always_inline)) {
+            constexpr int kk = decltype(uc)::value;
+            if (kk == 0) {
+                if (s + DY < S) issue_y(yslot == 0 ? YS - 1 : yslot - 1);
+            } else {
+                if (s + DX < S) issue_x(xslot == 0 ? XS - 1 : xslot - 1);
+            }
+            const int coff = (((kk * 4 + g0) ^ l7) << 4);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) fy[y] = *(const half8*)(ybuf + (wy * TY + y * 16 + l15) * 128 + coff);
+#pragma unroll
+            for (int x = 0; x < NX; ++x) fx[x] = *(const half8*)(xbuf + (wx * TX + x * 16 + l15) * 128 + coff);
+            if (kk == 0 && ks == 0) {       // a tile's first MFMAs start from zero
+                const float4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int y = 0; y < NY; ++y)
+#pragma unroll
+                    for (int x = 0; x < NX; ++x)
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int y = 0; y < NY; ++y)
+#pragma unroll
+                    for (int x = 0; x < NX; ++x)
+                        acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fx[x], fy[y], acc[y][x], 0, 0, 0);
+            }
+        };
+        unit(std::integral_constant<int, 0>{});
+        unit(std::integral_constant<int, 1>{});
+        const bool tile_end = ks == nk - 1;
+        // Gallery step s+1 and query slice s+1 must have landed before the next step reads them.
+        auto wait_ring = [&]() __attribute__((always_inline)) {
+            if (s + DX < S && s + DY < S) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (!tile_end) {
+            ++ks;
+            wait_ring();
+        } else {
+#if FR_DBG & 64
+            FR_STAMP(sc_ta);
+#endif
+            const long ptile = (WORK && tile_list) ? (long)tile_list[__builtin_amdgcn_readfirstlane((int)tile)] : tile;
+            const int rbase = (int)(ptile * 256) + wx * TX + g0 * 4;    // rows fit 31 bits (checked at launch)
+            const unsigned p = tdone & 1u;
+#if FR_DBG & 128
+            const bool boot = false;        // diagnostic: nothing is ever selected (the streaming floor)
+#else
+            const bool boot = tdone == 0;
+#endif
+            float thr[NY];
+            static_assert(NY == 2, "two query columns per lane");
+            auto read_thr = [&]() __attribute__((always_inline)) {
+                unsigned t0, t1;
+                lds_read_2u32_64(a_thr + qa, t0, t1);
+                thr[0] = ordered_value(t0); thr[1] = ordered_value(t1);
+            };
+            read_thr();
+#if FR_DBG & 128
+#pragma unroll
+            for (int y = 0; y < NY; ++y) thr[y] = INFINITY;
+#endif
+            // Nothing is queued unless some lane's best raw score reaches its query's threshold
+            // (striking rows out only lowers scores): the usual tile ends here, no key fetched.
+            bool some = boot;
+#pragma unroll
+            for (int y = 0; y < NY; ++y) {
+                const float4v (&a)[NX] = acc[y];
+                float mq = max3_raw(a[0][0], a[0][1], a[0][2]);
+                mq = max3_raw(mq, a[0][3], a[0][3]);
+#pragma unroll
+                for (int x = 1; x < NX; ++x) {
+                    mq = max3_raw(mq, a[x][0], a[x][1]);
+                    mq = max3_raw(mq, a[x][2], a[x][3]);
+                }
+                some = some || __any(mq >= thr[y]);
+            }
+            if (some) {
+                if (USE_KEYS) {
+                    // Key test: (key ^ kx) <= km as unsigned, with (kx, km) = (query key, 0) for an exact
+                    // match and (0, 0x7fffffff) for "any live row" (tombstones are negative).
+                    int4 kv[NX];
+#pragma unroll
+                    for (int x = 0; x < NX; ++x) kv[x] = *(const int4*)(gkeys + rbase + x * 16);   // padded allocation: in bounds
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        const int qq = q0 + wy * TY + y * 16 + l15;
+                        const int mykey = (qkeys && qq < bql) ? qkeys[qq] : -2;
+                        const unsigned kx = mykey == -2 ? 0u : (mykey < 0 ? 0x80000000u : (unsigned)mykey);
+                        const unsigned km = mykey == -2 ? 0x7fffffffu : 0u;
+#pragma unroll
+                        for (int x = 0; x < NX; ++x) {
+                            const unsigned k4[4] = {(unsigned)kv[x].x, (unsigned)kv[x].y, (unsigned)kv[x].z, (unsigned)kv[x].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[y][x][j] = ((k4[j] ^ kx) <= km) ? acc[y][x][j] : -INFINITY;
+                        }
+                    }
+                }
+                if ((ptile + 1) * 256 > nrows) {
+                    const int nr = (int)nrows;
+#pragma unroll
+                    for (int y = 0; y < NY; ++y)
+#pragma unroll
+                        for (int x = 0; x < NX; ++x)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[y][x][j] = (rbase + x * 16 + j < nr) ? acc[y][x][j] : -INFINITY;
+                }
+            }
+            wait_ring();
+#if FR_DBG & 64
+            unsigned long long sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;
+            FR_STAMP(sb0);
+#endif
+            if (boot) {
+                // A block's first tile: the 16 lists of a query (4 lanes x 4 waves) each put their best
+                // score into a table (the second queue's memory, unused until the second tile's end);
+                // after a barrier every list counts how many of the 16 reach its own: the largest
+                // score that at least K do is reached by K different rows, a first threshold.
+                unsigned mk[NY];
+#pragma unroll
+                for (int y = 0; y < NY; ++y) {
+                    const float4v (&v)[NX] = acc[y];
+                    float mq = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3])),
+                                     fmaxf(fmaxf(v[1][0], v[1][1]), fmaxf(v[1][2], v[1][3])));
+                    mq = fmaxf(mq, fmaxf(fmaxf(fmaxf(v[2][0], v[2][1]), fmaxf(v[2][2], v[2][3])),
+                                         fmaxf(fmaxf(v[3][0], v[3][1]), fmaxf(v[3][2], v[3][3]))));
+                    mk[y] = mq == mq ? ordered_key(mq) : 0u;          // (a NaN counts as no score)
+                    lds_write_u32(a_boot + (qa + (unsigned)(y * 64)) * 16 + (unsigned)((wx * 4 + g0) * 4), mk[y]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#if FR_DBG & 64
+                FR_STAMP(sb1);
+#endif
+#pragma unroll
+                for (int y = 0; y < NY; ++y) {
+                    unsigned k16[16];
+                    lds_read_16u32(a_boot + (qa + (unsigned)(y * 64)) * 16, k16);
+                    unsigned cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) cnt += k16[j] >= mk[y] ? 1u : 0u;
+                    if (cnt >= (unsigned)K && mk[y] >= LOWEST_KEY) lds_max_u32(a_thr + qa + (unsigned)(y * 64), mk[y]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                read_thr();
+#if FR_DBG & 64
+                FR_STAMP(sb2);
+#endif
+            }
+            for (;;) {
+                bool blocked = false;
+                if (some) {
+#pragma unroll
+                    for (int y = 0; y < NY; ++y) {
+                        float4v (&v)[NX] = acc[y];
+                        const float t = thr[y];
+                        // one reservation per lane: as many consecutive entries as it has survivors
+                        unsigned c = 0;
+#pragma unroll
+                        for (int x = 0; x < NX; ++x)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) c += v[x][j] >= t ? 1u : 0u;
+                        if (!__any(c != 0u)) continue;
+                        unsigned off = 0;
+                        if (c != 0u) off = lds_add_rtn_u32(a_cnt + p * 256 + qa + (unsigned)(y * 64), c);
+                        const unsigned ea = a_queue + p * (CAP * 512) + (qa + (unsigned)(y * 64)) * 2;
+#pragma unroll
+                        for (int x = 0; x < NX; ++x)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool pred = v[x][j] >= t;
+                                if (__any(pred)) {
+                                    if (pred) {
+                                        if (off < (unsigned)CAP) {
+                                            // {ordered key of the score, ~row}: the selector's list entry as it stands
+                                            const unsigned row = (unsigned)(rbase + x * 16 + j);
+                                            lds_write_u64(ea + off * 512, ((unsigned long long)ordered_key(v[x][j]) << 32) |
+                                                                              (unsigned long long)(~row));
+                                            v[x][j] = -INFINITY;
+                                        } else {
+                                            blocked = true;
+                                        }
+                                        ++off;
+                                    }
+                                }
+                            }
+                    }
+                }
+                if (__any(blocked)) lds_write_u32(a_ovf, chk + 1u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();               // A
+                __builtin_amdgcn_sched_barrier(0);
+                ++chk;
+                const bool again = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_read_u32(a_ovf)) == chk;
+                if (!again) break;
+#if FR_DBG & 64
+                ++sc_ovr;
+#endif
+                __builtin_amdgcn_s_barrier();               // B: the selector has drained and published
+                asm volatile("" ::: "memory");
+                read_thr();
+            }
+#if FR_DBG & 64
+            FR_STAMP(sb3);
+#endif
+            if (boot && chk == 1) {
+                // First tile, nothing overflowed: the queue holds every row of the tile that reached the
+                // first threshold, at most CAP per query.  Instead of the selector inserting them one by
+                // one (the whole chip would wait: every block is at its first tile), they are RANKED in
+                // parallel: wave w takes queries 8w..8w+7, eight lanes per query, lane (q, e) the entries
+                // e, e+8, ...; an entry's rank is the number of the query's entries with a larger key
+                // (keys differ: they hold the row), and ranks below K are the query's start list.
+                const unsigned qv = (unsigned)(8 * wave + (lane >> 3));
+                const unsigned cq = lds_read_u32(a_cnt + qv * 4);
+                const unsigned nq = cq < (unsigned)CAP ? cq : (unsigned)CAP;
+                constexpr int NE = CAP / 8;
+                unsigned long long mine[NE];
+                unsigned rank[NE];
+#pragma unroll
+                for (int t = 0; t < NE; ++t) {
+                    const unsigned j = (unsigned)(lane & 7) + 8u * (unsigned)t;
+                    const unsigned long long e = lds_read_u64(a_queue + ((j * 64) + qv) * 8);
+                    mine[t] = j < nq ? e : 0ull;
+                    rank[t] = 0u;
+                }
+                for (unsigned i4 = 0; __any(i4 < nq); i4 += 4) {
+                    unsigned long long e[4];
+                    lds_read_4u64(a_queue + ((i4 * 64) + qv) * 8, 512, e);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned long long eu = i4 + (unsigned)u < nq ? e[u] : 0ull;
+#pragma unroll
+                        for (int t = 0; t < NE; ++t) rank[t] += eu > mine[t] ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NE; ++t)
+                    if (mine[t] != 0ull && rank[t] < (unsigned)K)
+                        lds_write_u64(a_init + (qv * K + rank[t]) * 8, mine[t]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#if FR_DBG & 64
+            FR_STAMP(sc_tb);
+            if (tdone == 0) {
+                sc_boot = sc_tb - sc_ta;
+                if (tid == 0 && blockIdx.x < 256) {
+                    unsigned long long* const o = g_scan_stamp + blockIdx.x * 16;
+                    o[10] = sb0 - sc_ta; o[11] = sb1 - sb0; o[12] = sb2 - sb1; o[13] = sb3 - sb2; o[14] = sc_tb - sb3;
+                }
+            }
+            sc_sel += sc_tb - sc_ta; ++sc_n;
+            if (tid == 0 && blockIdx.x < 256 && tdone < 20) g_scan_tiles[blockIdx.x * 20 + tdone] = sc_tb - sc_t1;
+#endif
+            ++tdone;
+            ks = 0; tile += nb;
+        }
+        if (!tile_end) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        xslot = xslot == XS - 1 ? 0 : xslot + 1;
+        yslot = yslot == YS - 1 ? 0 : yslot + 1;
+    }
+#if FR_DBG & 64
+    FR_STAMP(sc_t2);
+    if (tid == 0 && blockIdx.x < 256) {
+        unsigned long long* const o = g_scan_stamp + blockIdx.x * 16;
+        o[0] = sc_t0; o[1] = sc_t1; o[2] = sc_t2; o[4] = sc_sel; o[5] = sc_n; o[7] = sc_boot; o[8] = sc_ovr;
+    }
+#endif
+}
+
 // Wave-wide unsigned max / min through DPP row shifts and row broadcasts: no LDS traffic, the
 // result is uniform.  Lanes without a source keep `identity`.
 FR_DEV unsigned wave_umax(unsigned v) {
@@ -2496,6 +3171,9 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStr
 hipError_t scan_debug_stamps(unsigned long long* out) {      // 256 x 16 values of the last scan launch
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_stamp), sizeof(unsigned long long) * 256 * 16);
 }
+hipError_t scan_debug_tiles(unsigned long long* out) {       // 256 x 20: selector kernel, tile end times
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_tiles), sizeof(unsigned long long) * 256 * 20);
+}
 #endif
 
 int scan_max_blocks() { return 256; }
@@ -2529,7 +3207,7 @@ size_t scan_part_entries(int Bq, int k) {
 // the array itself to a kernel or a memset: its name is a host-side stand-in, the device address
 // comes from hipGetSymbolAddress, once per device, below.
 constexpr size_t kScanStaticEntries = 256 * 256 * 5;
-constexpr size_t kScanStaticBoundBytes = 8192 * 16 * sizeof(unsigned);
+constexpr size_t kScanStaticBoundBytes = 8192 * 16 * sizeof(unsigned long long);
 constexpr size_t kScanStaticBytes = kScanStaticEntries * (sizeof(int64_t) + sizeof(float)) + kScanStaticBoundBytes;
 static __device__ __align__(256) unsigned char scratch[kScanStaticBytes];
 
@@ -2619,9 +3297,65 @@ static hipError_t scan_inst(const void* g, const int32_t* gk, long nrows, int D,
     return hipSuccess;
 }
 
+// The 64-query tile with a selector wave (scan_sel_kernel): rings of 3 gallery and 3 query stages,
+// queues of 32 entries.
+static int g_sel_variant = 1;            // 0: the kernel without a selector wave (A/B runs of the micro-benchmark)
+void scan_set_sel_variant(int v) { g_sel_variant = v; }
+
+// Launch number that tags the cross-block bound slots: 40 bits, never 0, different in every launch of
+// the process (ONE counter for all instantiations: two launches on one slot array must never share it).
+static unsigned long long scan_next_launch_number() {
+    static std::atomic<unsigned long long> launches{0};
+    unsigned long long g;
+    do g = (launches.fetch_add(1) + 1) & ((1ull << 40) - 1); while (g == 0);
+    return g;
+}
+
+template <int K, bool USE_KEYS, bool WORK, int XS, int YS, int CAP>
+static hipError_t scan_sel_inst(const void* g, const int32_t* gk, long nrows, int D, const void* q,
+                                const int32_t* qkeys, int Bq, int nb, float* part_s, int64_t* part_r,
+                                unsigned* qbound, hipStream_t s, bool attr_only, const int32_t* tile_list = nullptr,
+                                long ntl = 0, const ScanWork* work = nullptr, int nwork = 0) {
+    constexpr int lds = XS * 256 * 128 + YS * 64 * 128 + 1024 + 2 * CAP * 64 * 8;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = scan_sel_kernel<K, USE_KEYS, WORK, XS, YS, CAP>;
+    if (attr_only) return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int qtiles = (Bq + 63) / 64;
+    const unsigned long long gen = scan_next_launch_number();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(work ? nwork : nb * qtiles)), dim3(576), lds, s, (const half_t*)g, gk,
+                       nrows, D, (const half_t*)q, qkeys, Bq, nb, part_s, (long long*)part_r, qbound, tile_list, ntl,
+                       work, gen);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+template <int K, bool USE_KEYS, bool WORK>
+static hipError_t scan_sel_variants(const void* g, const int32_t* gk, long nrows, int D, const void* q,
+                                    const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr, unsigned* qb,
+                                    hipStream_t s, bool attr, const int32_t* tile_list = nullptr, long ntl = 0,
+                                    const ScanWork* work = nullptr, int nwork = 0) {
+    if (attr) {
+        hipError_t e = scan_sel_inst<K, USE_KEYS, WORK, 3, 3, 32>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, true);
+        return e;
+    }
+    return scan_sel_inst<K, USE_KEYS, WORK, 3, 3, 32>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, false, tile_list,
+                                                      ntl, work, nwork);
+}
+
 static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const int32_t* gk, long nrows, int D,
                                 const void* q, const int32_t* qkeys, int Bq, int nb, float* ps, int64_t* pr,
                                 unsigned* qb, hipStream_t s, bool attr) {
+#define FR_SCANSEL(K)                                                                                         \
+    if (kl == K && ry == 64 && (attr || g_sel_variant != 0)) {                                                \
+        const hipError_t e =                                                                                  \
+            keys ? scan_sel_variants<K, true, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr)  \
+                 : scan_sel_variants<K, false, false>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr); \
+        if (!attr || e != hipSuccess) return e;                                                               \
+    }
+    FR_SCANSEL(5)
+    FR_SCANSEL(10)
+    FR_SCANSEL(16)
+#undef FR_SCANSEL
 #define FR_SCAN(K, RY, WX, WY)                                                                              \
     if (kl == K && ry == RY)                                                                                  \
         return keys ? scan_inst<K, RY, WX, WY, true>(g, gk, nrows, D, q, qkeys, Bq, nb, ps, pr, qb, s, attr)  \
@@ -2641,10 +3375,11 @@ static hipError_t scan_dispatch(int kl, int ry, bool keys, const void* g, const 
 static int g_bound_min_tiles = -1;       // < 0: the built-in rule below
 void scan_set_bound_min_tiles(int t) { g_bound_min_tiles = t; }      // tuning hook of the micro-benchmark
 
-size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 16 * sizeof(unsigned); }
+size_t scan_bound_bytes(int Bq) { return (((size_t)Bq + 255) & ~(size_t)255) * 16 * sizeof(unsigned long long); }
 
-// `qbound`: scan_bound_bytes(Bq) bytes of device scratch for the cross-block score bounds (cleared
-// here, on the stream, before the kernel), or null to scan without them.
+// `qbound`: scan_bound_bytes(Bq) bytes of device scratch for the cross-block score bounds, zeroed once
+// when allocated (the kernels without a selector wave clear it here, on the stream, before they run; the
+// selector kernel's slots carry the launch's number and are never cleared), or null to scan without them.
 hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int D, const void* q,
                             const int32_t* qkeys, int use_keys, int Bq, int k, float* part_s, int64_t* part_r,
                             unsigned* qbound, int* nblk_out, hipStream_t s) {
@@ -2664,9 +3399,12 @@ hipError_t launch_scan_topk(const void* g, const int32_t* gk, int64_t nrows, int
     // The bounds pay once a block walks enough tiles to amortise their reads (and the clearing launch):
     // measured break-even near 20 tiles for the HBM-bound 64-query tile and below 8 for the wider,
     // MFMA-bound tiles, whose tile-end selection the bounds shorten most.
-    const int min_tiles = g_bound_min_tiles >= 0 ? g_bound_min_tiles : (ry >= 128 ? 8 : 24);
+    // (the 64-query tile's selector wave exchanges them beside the stream and its slots need no clearing,
+    // but every exchange still disturbs all blocks' streams: same break-even)
+    const bool sel = ry == 64 && g_sel_variant != 0;
+    const int min_tiles = g_bound_min_tiles >= 0 ? g_bound_min_tiles : (sel ? 3 : ry >= 128 ? 8 : 24);
     if (ntiles / nb < min_tiles) qbound = nullptr;
-    if (qbound) {
+    if (qbound && !sel) {
         hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq), s);
         if (e != hipSuccess) return e;
     }
@@ -2689,14 +3427,17 @@ hipError_t launch_scan_topk_work(const void* g, const int32_t* gk, int64_t nrows
         return hipErrorInvalidValue;
     if ((uint64_t)Bq * (uint64_t)D * 2 >= (1ull << 32) || (uint64_t)D * 512 >= (1ull << 32)) return hipErrorInvalidValue;
     const int kl = scan_klist(k);
-    if (qbound) {
+    if (qbound && g_sel_variant == 0) {
         hipError_t e = hipMemsetAsync(qbound, 0, scan_bound_bytes(Bq + 64), s);
         if (e != hipSuccess) return e;
     }
 #define FR_SCANW(K)                                                                                           \
     if (kl == K)                                                                                              \
-        return scan_inst<K, 64, 4, 2, true, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r, qbound, s,  \
-                                                  false, tile_lists, 0, work, nwork);
+        return g_sel_variant != 0                                                                             \
+                   ? scan_sel_variants<K, true, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r, qbound, \
+                                                      s, false, tile_lists, 0, work, nwork)                   \
+                   : scan_inst<K, 64, 4, 2, true, true>(g, gk, (long)nrows, D, q, qkeys, Bq, 1, part_s, part_r,       \
+                                                        qbound, s, false, tile_lists, 0, work, nwork);
     FR_SCANW(5)
     FR_SCANW(10)
     FR_SCANW(16)
@@ -2764,6 +3505,12 @@ hipError_t kernels_init() {
             if (e != hipSuccess) return e;
         }
     // the work-list instantiations (search by key)
+    e = scan_sel_variants<5, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    if (e == hipSuccess)
+        e = scan_sel_variants<10, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    if (e == hipSuccess)
+        e = scan_sel_variants<16, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
+    if (e != hipSuccess) return e;
     e = scan_inst<5, 64, 4, 2, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);
     if (e == hipSuccess)
         e = scan_inst<10, 64, 4, 2, true, true>(nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, true);

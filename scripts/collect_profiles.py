@@ -45,8 +45,9 @@ def main():
     wanted = {
         "scan_topk_kernel<5,256>": ("scan_topk_kernelILi5ELi256E", {"rows": cfg["gallery_rows"], "dim": cfg["dim"],
                                                                      "queries": cfg["batch_per_gpu"], "k": cfg["k"]}),
-        "scan_topk_kernel<10,64>": ("scan_topk_kernelILi10ELi64E", {"rows": 1_000_000, "dim": cfg["dim"],
-                                                                     "queries": 64, "k": 10}),
+        # (the 64-query tile with the selector wave; no key filter, whole-gallery form)
+        "scan_sel_kernel<10>": ("scan_sel_kernelILi10ELb0ELb0E", {"rows": 1_000_000, "dim": cfg["dim"],
+                                                                  "queries": 64, "k": 10}),
     }
     doc = {"run": run, "source": f"profiles/{run}_bench_pmc_fetch_write.csv",
            "correction": "FETCH_SIZE x2 (gfx950 counts 64-B units as 32 B), WRITE_SIZE as is; KiB x 1024", "kernels": {}}

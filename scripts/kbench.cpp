@@ -18,7 +18,7 @@ using namespace frhot;
 namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
 #endif
 #if FR_DBG & 64
-namespace frhot { hipError_t scan_debug_stamps(unsigned long long* out); }
+namespace frhot { hipError_t scan_debug_stamps(unsigned long long* out); hipError_t scan_debug_tiles(unsigned long long* out); }
 #include <algorithm>
 #endif
 
@@ -182,7 +182,10 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
     CK(hipMalloc((void**)&ps, (size_t)scan_max_blocks() * Bq * kl * 4));
     CK(hipMalloc((void**)&pr, (size_t)scan_max_blocks() * Bq * kl * 8));
     unsigned* qb = nullptr;
-    if (!getenv("KBENCH_NO_BOUND")) CK(hipMalloc((void**)&qb, scan_bound_bytes(Bq)));
+    if (!getenv("KBENCH_NO_BOUND")) {
+        CK(hipMalloc((void**)&qb, scan_bound_bytes(Bq)));
+        CK(hipMemset(qb, 0, scan_bound_bytes(Bq)));
+    }
     int nblk = 0;
     const float ms = time_ms(
         [&] { CK(launch_scan_topk(g, gk, N, D, q, qk, use_keys, Bq, k, ps, pr, qb, &nblk, s)); }, 3, 40, s);
@@ -211,11 +214,30 @@ static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream
         }
         auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
         auto mx = [](const std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
+        printf("   [selector kernel: loop end -> selector exit in place of the merge tail; 'before the groups' = first tile's end, "
+               "'group preludes' = overflow rounds, 'insertion loops' = selector drain cycles, rounds = selector rounds]\n");
         printf("   stamps (cycles, wave 0; median / max over %d blocks): prologue %.0f / %.0f  loop %.0f / %.0f  merge tail %.0f / %.0f\n"
                "      tile ends: %.0f in all, %.0f / %.0f cycles  = before the groups %.0f + group preludes %.0f + insertion loops %.0f "
                "(%.0f / %.0f rounds)\n",
                nbk, med(col[0]), mx(col[0]), med(col[1]), mx(col[1]), med(col[2]), mx(col[2]), med(col[4]), med(col[3]), mx(col[3]),
                med(col[6]), med(col[7]), med(col[8]), med(col[5]), mx(col[5]));
+        static unsigned long long tl[256 * 20];
+        CK(frhot::scan_debug_tiles(tl));
+        {
+            std::vector<double> ph[5];
+            for (int b = 0; b < nbk; ++b)
+                for (int i = 0; i < 5; ++i) ph[i].push_back((double)st[b * 16 + 10 + i]);
+            printf("      first tile's end: test+strike+ring wait %.0f, best-score table -> barrier %.0f, count -> barrier %.0f, "
+                   "queue -> barrier -> flag %.0f, ranking -> barrier %.0f\n",
+                   med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
+        }
+        printf("      tile durations (median over blocks, wave 0):");
+        for (int t = 0; t < 16; ++t) {
+            std::vector<double> v;
+            for (int b = 0; b < nbk; ++b) v.push_back((double)tl[b * 20 + t] - (t ? (double)tl[b * 20 + t - 1] : 0.0));
+            printf(" %.0f", med(v));
+        }
+        printf("\n");
     }
 #endif
     CK(hipFree(os)); CK(hipFree(orr));
@@ -240,6 +262,24 @@ static void bench_scan() {
     if (getenv("KBENCH_D4096")) {         // the reference's descriptor length at serving-sized query counts
         for (int bq : {1, 8, 64, 128, 256}) bench_scan_one(1000000, 4096, bq, 5, 0, s);
         bench_scan_one(1000000, 4096, 64, 5, 1, s);
+        CK(hipStreamDestroy(s));
+        return;
+    }
+    if (getenv("KBENCH_SEL")) {           // 64-query tile: without (0) and with the selector wave (1, 2), same process
+        const int rounds = atoi(getenv("KBENCH_SEL")) > 0 ? atoi(getenv("KBENCH_SEL")) : 2;
+        for (int r = 0; r < rounds; ++r)
+            for (int v : {0, 1}) {
+                if (getenv("KBENCH_SELV") && !strchr(getenv("KBENCH_SELV"), '0' + v)) continue;
+                scan_set_sel_variant(v);
+                printf("-- selector variant %d (round %d)\n", v, r);
+                bench_scan_one(1000000, 512, 64, 10, 0, s);
+                bench_scan_one(1000000, 512, 64, 5, 0, s);
+                bench_scan_one(2000000, 512, 64, 10, 0, s);
+                bench_scan_one(10000000, 512, 64, 10, 0, s);
+                bench_scan_one(1000000, 4096, 64, 5, 0, s);
+                bench_scan_one(1000000, 512, 64, 10, 1, s);
+            }
+        scan_set_sel_variant(1);
         CK(hipStreamDestroy(s));
         return;
     }

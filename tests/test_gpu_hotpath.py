@@ -293,6 +293,40 @@ def test_search_long_scan_matches_oracle(gpu_ctx, n, d, bq, k, with_keys):
     gal.close()
 
 
+@pytest.mark.parametrize("k,d", [(10, 64), (5, 128), (16, 64)])
+def test_search_many_equal_scores_in_one_tile(gpu_ctx, k, d):
+    """More survivors of one query in one 256-row tile than the 64-query scan's selection queue holds
+    (32): whole tiles of identical rows, once in a tile that is some block's FIRST (where the start
+    lists are ranked, not inserted) and once in a later tile of a block, plus a run that straddles two
+    tiles.  Equal scores come back in ascending row order, so the answer is exact and unique; queries
+    that match nothing special ride along in the same query tile."""
+    from frhot.engine import Gallery
+    from oracle import search as osr
+    rng = np.random.default_rng(k * 1000 + d)
+    n = 150_000                                    # 586 tiles on 256 blocks: blocks walk 2 or 3 tiles
+    g = rng.standard_normal((n, d), dtype=np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    va, vb, vc = (rng.standard_normal(d).astype(np.float32) for _ in range(3))
+    g[5 * 256:6 * 256] = va                         # tile 5: block 5's first tile
+    g[300 * 256:301 * 256] = vb                     # tile 300: block 44's second tile
+    g[520 * 256 - 40:520 * 256 + 45] = vc           # 85 rows over the end of tile 519 and the start of tile 520
+    bq = 64
+    q = rng.standard_normal((bq, d), dtype=np.float32)
+    q[3], q[17], q[40] = va, vb, vc
+    q[41] = va + vb                                 # both tiles of equal rows score high for one query
+    gal = Gallery(gpu_ctx, d, n)
+    for lo in range(0, n, 50_000):
+        gal.upsert(g[lo:lo + 50_000], 0, np.arange(lo, min(n, lo + 50_000)))
+    got_s, got_r = gal.search(q, None, k)
+    ref_s, ref_r = osr.cosine_topk(q, g, k, gallery_dtype=np.float16)
+    assert np.array_equal(got_r[3], 5 * 256 + np.arange(k))
+    assert np.array_equal(got_r[17], 300 * 256 + np.arange(k))
+    assert np.array_equal(got_r[40], 520 * 256 - 40 + np.arange(k))
+    assert np.array_equal(got_r, ref_r)
+    assert np.abs(got_s - ref_s).max() <= 2e-5
+    gal.close()
+
+
 def test_search_key_filter_and_tombstones(gpu_ctx):
     from frhot import synth
     from frhot.engine import Gallery
