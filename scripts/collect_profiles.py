@@ -58,6 +58,29 @@ def main():
         fk, wk = fetch[hit[0]][1], write.get(hit[0], (0, 0.0))[1]
         doc["kernels"][label] = {"workload": workload, "fetch_kib": round(fk), "write_kib": round(wk),
                                  "traffic_bytes": int(round((2 * fk + wk) * 1024))}
+    # scan-only shapes measured in counter passes of their own (bench.py --scan-shape-only)
+    extra = {
+        "rank8": ("scan_topk_kernel<5,256> at one rank's 8-GPU shape", "scan_topk_kernelILi5ELi256E",
+                  {"rows": 1_250_000, "dim": 512, "queries": 2048, "k": 5}),
+        "10m_q64": ("scan_sel_kernel<5> on the headline gallery", "scan_sel_kernelILi5ELb0ELb0E",
+                    {"rows": 10_000_000, "dim": 512, "queries": 64, "k": 5}),
+    }
+    for shape, (label, needle, workload) in extra.items():
+        fdir = glob.glob(os.path.join(src, f"pmc_FETCH_{shape}", "*", "*counter_collection.csv"))
+        wdir = glob.glob(os.path.join(src, f"pmc_WRITE_{shape}", "*", "*counter_collection.csv"))
+        if not fdir or not wdir:
+            continue
+        f2, w2 = mean_counter(fdir[0], "FETCH_SIZE"), mean_counter(wdir[0], "WRITE_SIZE")
+        hit = [k for k in f2 if needle in k]
+        if not hit:
+            continue
+        fk, wk = f2[hit[0]][1], w2.get(hit[0], (0, 0.0))[1]
+        doc["kernels"][label] = {"workload": workload, "fetch_kib": round(fk), "write_kib": round(wk),
+                                 "traffic_bytes": int(round((2 * fk + wk) * 1024)),
+                                 "source": f"separate rocprofv3 --pmc passes of bench.py --scan-shape-only {shape}"}
+    long_run = os.path.join(src, "bench_2000_steps.json")
+    if os.path.exists(long_run):
+        shutil.copy(long_run, os.path.join(dst, f"{run}_bench_2000_steps.json"))
     with open(os.path.join(dst, f"{run}_pmc_traffic.json"), "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc["kernels"], indent=1))
