@@ -24,7 +24,7 @@ import torch.distributed as dist
 class ShardedSearch:
     def __init__(self, world: int, batch: int, dim: int, k: int, device,
                  search_local: Callable, merge: Callable, qdtype=torch.float16, always_exchange: bool = False,
-                 drain_before_exchange: bool = False):
+                 drain_before_exchange: bool = False, host_staged: bool = False):
         """search_local(q_all, scores_out, rows_out[, qkeys_all]): fill [P*B,k] float32 / int64 (global
         rows, -1 = none); the fourth argument (int32 [P*B], same device) is passed only by calls that
         carry keys.  merge(s_all, r_all, out_s, out_r): [P,P*B,k] -> [P*B,k]; s_all and r_all are
@@ -41,6 +41,10 @@ class ShardedSearch:
         # pending kernels was seen to stall for minutes (the processes' queues are time-sliced),
         # while a gather on an idle device completes at once.  One rank per GPU never needs it.
         self.drain = drain_before_exchange
+        # host_staged: the collectives run on host copies of the device buffers (a backend without
+        # device support: gloo, whose own staging of device tensors was seen to stall now and then
+        # between processes that share one GPU).  RCCL gathers the device buffers themselves.
+        self.host_staged = host_staged and torch.device(device).type != "cpu"
         n = world * batch
         self.q_all = torch.empty((n, dim), dtype=qdtype, device=device) if self.exchange else None
         # A shard's answer travels as ONE block: its rows (int64 [n,k]) followed by its scores
@@ -62,6 +66,10 @@ class ShardedSearch:
             self.out_s = torch.empty((n, k), dtype=torch.float32, device=device)
             self.out_r = torch.empty((n, k), dtype=torch.int64, device=device)
             self.k_all = torch.empty(n, dtype=torch.int32, device=device)
+            if self.host_staged:
+                self._q_h = torch.empty((n, dim), dtype=qdtype)
+                self._k_h = torch.empty(n, dtype=torch.int32)
+                self._p_h = torch.empty((world, self._words), dtype=torch.int64)
 
     def __call__(self, q_local: torch.Tensor, qkeys_local: torch.Tensor | None = None):
         """q_local [B, D] unit rows of this rank (and, for a search inside collections, their int32
@@ -73,20 +81,34 @@ class ShardedSearch:
             else:
                 self.search_local(q_local, self.s_local, self.r_local, qkeys_local)
             return self.s_local, self.r_local
-        if self.drain and self.q_all.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        dist.all_gather_into_tensor(self.q_all, q_local)
+        self._drain()
+        self._gather(self.q_all, q_local, "_q_h")
         if qkeys_local is None:
             self.search_local(self.q_all, self.s_local, self.r_local)
         else:
-            dist.all_gather_into_tensor(self.k_all, qkeys_local.to(torch.int32).contiguous())
+            self._drain()
+            self._gather(self.k_all, qkeys_local.to(torch.int32).contiguous(), "_k_h")
             self.search_local(self.q_all, self.s_local, self.r_local, self.k_all)
-        if self.drain and self.q_all.is_cuda:
-            torch.cuda.current_stream().synchronize()
+        self._drain()
         # the gather output is passed flat (rank-major): gloo rejects the stacked shape
-        dist.all_gather_into_tensor(self.packed_all.view(-1), self.packed)
+        self._gather(self.packed_all.view(-1), self.packed, "_p_h")
         self.merge(self.s_all, self.r_all, self.out_s, self.out_r)
         return self.out_s, self.out_r
+
+
+    def _gather(self, out: torch.Tensor, mine: torch.Tensor, mirror: str):
+        if not self.host_staged:
+            dist.all_gather_into_tensor(out, mine)
+            return
+        h = getattr(self, mirror)
+        dist.all_gather_into_tensor(h.view(-1), mine.cpu().view(-1))      # (.cpu() waits for the producer)
+        out.view(-1).copy_(h.view(-1))
+
+    def _drain(self):
+        # everything this process has queued on the device, on any stream (the staging copies of the
+        # collective before this one included)
+        if self.drain and self.q_all.is_cuda:
+            torch.cuda.synchronize(self.q_all.device)
 
 
 def shard_rows(total_rows: int, world: int, rank: int):

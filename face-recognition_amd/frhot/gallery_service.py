@@ -146,8 +146,9 @@ class GalleryService:
             self._drop_rows(rows[:len(rows) - limit + 1])
 
     def insert_point(self, collection_name, vector_embedding, id, name, store_id, is_update_id=False,
-                     time_created=None):
-        """app.py:242-297."""
+                     time_created=None, uid=None):
+        """app.py:242-297.  `uid`: the point's id (a fresh uuid4, app.py:288, unless the caller brings
+        one: replicas of this table that apply the same insert must agree on it)."""
         if time_created is None:
             time_created = datetime.datetime.now().strftime("%Y/%m/%d %H:%M:%S")
         if collection_name == "" or collection_name is None:
@@ -185,7 +186,7 @@ class GalleryService:
                     self._rows.release(row)         # the row was never written: hand it back
                     raise
                 self._seq += 1
-                self._points[row] = {"uid": str(uuid.uuid4()), "payload": payload, "collection": collection_name,
+                self._points[row] = {"uid": uid or str(uuid.uuid4()), "payload": payload, "collection": collection_name,
                                      "seq": self._seq}
                 self._by_id.setdefault((collection_name, id), []).append(row)
                 return 201, {"message": "Point inserted"}
@@ -245,15 +246,20 @@ class GalleryService:
                 idx.append(i)
                 vecs.append(np.asarray(vec, dtype=np.float32))
                 keys.append(k)
-            if idx:
+            if idx or self._always_search:
                 try:
-                    scores, rows = self.gallery.search(np.stack(vecs), np.asarray(keys, np.int32), SEARCH_LIMIT)
+                    scores, rows = self._search_batch(vecs, keys)
                     for j, i in enumerate(idx):
                         out[i] = (200, vote(self._hits(scores[j], rows[j])))
                 except Exception as e:
                     for i in idx:
                         out[i] = (404, {"message": str(e)})
             return out
+
+    _always_search = False   # (a sharded gallery's search is a collective: every rank makes the call, with or without queries)
+
+    def _search_batch(self, vecs, keys):
+        return self.gallery.search(np.stack(vecs), np.asarray(keys, np.int32), SEARCH_LIMIT)
 
     NO_KEY = 0x7FFFFFFF      # a query key no row carries: the crop is still embedded, nothing matches
 
@@ -267,6 +273,8 @@ class GalleryService:
         as search_point; needs a gallery created on a frhot.engine.Context.  `want_sharpness`: every
         answer carries a fourth item, the crop's Laplacian variance before the LUT (the measure of
         the blur gate, legacy.py:125-129), from the same device call."""
+        if not requests:
+            return []
         with self._lock:
             out = [None] * len(requests)
             keys, bad = [], {}

@@ -1088,3 +1088,54 @@ def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
         gal.close()
     assert np.array_equal(got_r, want_r + base)
     assert np.abs(got_s - want_s).max() <= 2e-3        # the host call normalises float32 queries; here they arrive as fp16
+
+
+def test_sharded_service_one_rank_equals_single_service(gpu_ctx):
+    """ShardedGalleryService over the HIP backend with ONE rank (no process group: the collectives
+    fall away, everything else runs: global-row placement, the device-pointer embed, the search by key
+    with a row base) against GalleryService on the same GPU: enrolments, an eviction run past ten
+    faces of one id, a deletion, and fused recognitions of crops answer identically."""
+    import torch
+
+    from frhot import synth
+    from frhot.engine import Gallery
+    from frhot.gallery_service import GalleryService
+    from frhot.sharded_service import HipShardBackend, ShardedGalleryService
+    dev = torch.device("cuda", 0)
+    cap = 2048
+    single = GalleryService(gpu_ctx, capacity=cap)
+    svc = ShardedGalleryService(HipShardBackend(gpu_ctx, Gallery(gpu_ctx, 4096, cap), 0, cap, dev), 0, 1, cap, 4096,
+                                batch=16)
+    crops = synth.crops(seed=91, n=14, lo=120, hi=260)
+    emb = gpu_ctx.embed(crops, gamma=True)
+    for s in (single, svc):
+        assert s.create_collection("S_Employees")[0] == 201 and s.create_collection("S_Customers")[0] == 201
+    ops = []
+    for i in range(6):
+        ops.append(("insert_point", dict(collection_name="S_Employees", vector_embedding=emb[i].tolist(), id=str(i),
+                                         name=f"n{i}", store_id="S", time_created=f"2026/01/01 00:00:{i:02d}")))
+    for j in range(12):         # twelve faces of one id: the limit of ten evicts the oldest
+        ops.append(("insert_point", dict(collection_name="S_Customers", vector_embedding=emb[6 + j % 4].tolist(), id="77",
+                                         name="many", store_id="S", time_created=f"2026/01/01 00:01:{j:02d}")))
+    ops.append(("delete_point", "S_Employees", "3"))
+    got = svc.mutate(ops)
+    want = [single.insert_point(**op[1]) if op[0] == "insert_point" else single.delete_point(op[1], op[2]) for op in ops]
+    assert got == want
+    assert svc.point_count("S_Customers") == single.point_count("S_Customers") == 10
+    reqs = [("S_Employees", crops[i], "S") for i in range(6)] + [("S_Customers", crops[7], "S"), ("S_Employees", crops[12], "S"),
+                                                                  ("nowhere", crops[0], "S"), ("S_Employees", crops[1], "T")]
+    a = single.recognise_points(reqs, gamma=True)
+    b = svc.recognise_points(reqs, gamma=True)
+    assert len(a) == len(b) == len(reqs)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0] and x[1]["message"] == y[1]["message"], (i, x, y)
+        if x[1].get("data"):
+            assert x[1]["data"][0][1] == y[1]["data"][0][1] and abs(x[1]["data"][0][0] - y[1]["data"][0][0]) < 1e-6
+    assert a[0][1]["data"][0][1]["id"] == "0" and a[8][0] == 404 and a[9][1]["data"] == []
+    sv = [(c, emb[i].tolist(), s) for i, (c, _crop, s) in enumerate(reqs[:6])]
+    for x, y in zip(single.search_points(sv), svc.search_points(sv)):
+        assert x[0] == y[0] and x[1]["message"] == y[1]["message"]
+        if x[1].get("data"):
+            assert x[1]["data"][0][1] == y[1]["data"][0][1] and abs(x[1]["data"][0][0] - y[1]["data"][0][0]) < 1e-6
+    svc.close()
+    single.close()
