@@ -18,20 +18,25 @@ def _ptr(a: np.ndarray, ctype):
 
 
 def _crop_args(images):
-    n = len(images)
+    """(objects to keep alive, pointer array, [n,2] heights and widths, row strides) of n crops.
+    Addresses come from the arrays' interface dictionaries: one ctypes pointer object per crop
+    cost a batch of 256 about a millisecond."""
     arrs = []
     for im in images:
-        im = np.asarray(im)
+        if type(im) is not np.ndarray:
+            im = np.asarray(im)
         if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
             raise ValueError("crops must be uint8 arrays of shape [h, w, 3] (BGR)")
-        if im.strides[2] != 1 or im.strides[1] != 3 or im.strides[0] < 3 * im.shape[1]:
+        st = im.strides
+        if st[2] != 1 or st[1] != 3 or st[0] < 3 * im.shape[1]:
             im = np.ascontiguousarray(im)
         arrs.append(im)
-    ptrs = (C.POINTER(C.c_uint8) * n)(*[_ptr(a, C.c_uint8) for a in arrs])
-    hw = np.asarray([(a.shape[0], a.shape[1]) for a in arrs], dtype=np.int32).reshape(n, 2)
-    strides = np.asarray([a.strides[0] for a in arrs], dtype=np.int32)
-    return arrs, ptrs, hw, strides
-
+    n = len(arrs)
+    addr = np.fromiter((a.__array_interface__["data"][0] for a in arrs), dtype=np.uint64, count=n)
+    hw = np.array([a.shape[:2] for a in arrs], dtype=np.int32).reshape(n, 2)
+    strides = np.fromiter((a.strides[0] for a in arrs), dtype=np.int32, count=n)
+    ptrs = addr.ctypes.data_as(C.POINTER(C.POINTER(C.c_uint8)))
+    return (arrs, addr), ptrs, hw, strides
 
 
 def laplacian_variance(sums, hw) -> np.ndarray:
