@@ -1,11 +1,14 @@
 // C ABI of libfrhot.so (see include/frhot.h): contexts, model loading, the embed
 // pipeline, galleries and search.  Host-side only; kernels live in frhot_kernels.hip.
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is bound at run time (dlopen)
+#include <dlfcn.h>
 
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -151,6 +154,11 @@ struct frhot_ctx {
     float* res_s = nullptr; int64_t* res_r = nullptr;  // [B,16]
     int64_t* sharp_dev = nullptr;                      // [B,2]
     std::vector<CropMeta> meta_host;
+    // the communicator of a row-sharded search and its exchange buffers (frhot_dist_init)
+    void* comm = nullptr; int dist_rank = 0, dist_world = 0;
+    void* xq = nullptr; size_t xq_cap = 0;           // every rank's queries, fp16 [world*B, D]
+    int32_t* xk = nullptr; size_t xk_cap = 0;        // every rank's keys [world*B]
+    int64_t* xblk = nullptr; size_t xblk_cap = 0;    // this shard's answer block, then the world's blocks (int64 words)
     // timing: per stage a ring of (begin, end) event pairs; n[i] counts recorded pairs
     bool timing = false;
     static constexpr int kRing = 128;
@@ -167,6 +175,8 @@ struct frhot_ctx {
         return rc;
     }
 };
+
+static void dist_release(frhot_ctx* c);
 
 struct frhot_gallery {
     frhot_ctx* ctx = nullptr;
@@ -883,6 +893,7 @@ int frhot_ctx_destroy(frhot_ctx* c) {
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    dist_release(c);
     void* ptrs[] = {c->x0, c->u8, c->img_max, c->meta_dev, c->lut_dev, c->fc6_out, c->partial,
                     c->emb_dev, c->q_dev, c->qkeys_dev, c->res_s, c->res_r, c->sharp_dev, c->w6, c->w7, c->b6, c->b7};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1384,6 +1395,162 @@ int frhot_merge_topk_packed_dev(frhot_ctx* c, const void* packed_dev, int64_t sh
     HIP_TRY(launch_topk_final((const float*)(b + n * 8), (const int64_t*)b, P, k, Bq, k, 0, (float*)out_scores_dev,
                               (int64_t*)out_rows_dev, c->stream, nullptr, nullptr, shard_stride_bytes / 4,
                               shard_stride_bytes / 8));
+    return FRHOT_OK;
+    });
+}
+
+// ---- the row-sharded search with the exchange inside the library -----------------------------
+// RCCL is bound at run time: a process that never shards never loads it, and one whose host
+// framework already holds a copy (torch ships its own) gets that copy, not a second one.
+namespace {
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string why;
+};
+
+std::string g_rccl_why;     // why the last attempt to load it failed (guarded by the mutex in rccl())
+
+Rccl* rccl() {
+    static std::mutex m;
+    static Rccl r;
+    std::lock_guard<std::mutex> lk(m);
+    if (r.so) return &r;
+    const char* env = getenv("FRHOT_RCCL_LIB");
+    const char* names[] = {env && *env ? env : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* so = nullptr;
+    r.why.clear();
+    for (const char* n : names) {
+        if (!n) continue;
+        so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (so) break;
+        const char* e = dlerror();
+        r.why += std::string(n) + ": " + (e ? e : "?") + "; ";
+        if (n == env) break;                        // a library named by the caller is the only one tried
+    }
+    if (!so) { g_rccl_why = r.why; return nullptr; }
+    r.get_unique_id = (decltype(r.get_unique_id))dlsym(so, "ncclGetUniqueId");
+    r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(so, "ncclCommInitRank");
+    r.comm_destroy = (decltype(r.comm_destroy))dlsym(so, "ncclCommDestroy");
+    r.all_gather = (decltype(r.all_gather))dlsym(so, "ncclAllGather");
+    r.error_string = (decltype(r.error_string))dlsym(so, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.error_string) {
+        r.why = "the library lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
+        g_rccl_why = r.why;
+        dlclose(so);
+        return nullptr;
+    }
+    r.so = so;
+    return &r;
+}
+
+int grow(void** p, size_t* cap, size_t need_bytes) {
+    if (*cap >= need_bytes) return FRHOT_OK;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIP_TRY(hipMalloc(p, need_bytes));
+    *cap = need_bytes;
+    return FRHOT_OK;
+}
+}  // namespace
+
+#define RCCL_TRY(r, expr)                                                                        \
+    do {                                                                                         \
+        const ncclResult_t e_ = (expr);                                                          \
+        if (e_ != ncclSuccess) return fail(FRHOT_EHIP, "%s failed: %s", #expr, (r)->error_string(e_)); \
+    } while (0)
+
+static void dist_release(frhot_ctx* c) {
+    if (c->comm) {
+        if (Rccl* r = rccl()) (void)r->comm_destroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    c->dist_world = 0; c->dist_rank = 0;
+    if (c->xq) (void)hipFree(c->xq);
+    if (c->xk) (void)hipFree(c->xk);
+    if (c->xblk) (void)hipFree(c->xblk);
+    c->xq = nullptr; c->xk = nullptr; c->xblk = nullptr;
+    c->xq_cap = c->xk_cap = c->xblk_cap = 0;
+}
+
+int frhot_dist_unique_id(void* id_out) {
+    return guarded([&]() -> int {
+    if (!id_out) return fail(FRHOT_EINVAL, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+    Rccl* r = rccl();
+    if (!r) return fail(FRHOT_ESTATE, "RCCL could not be loaded (%s)", g_rccl_why.c_str());
+    ncclUniqueId id;
+    RCCL_TRY(r, r->get_unique_id(&id));
+    memcpy(id_out, &id, sizeof id);
+    return FRHOT_OK;
+    });
+}
+
+int frhot_dist_init(frhot_ctx* c, int rank, int world, const void* id_bytes) {
+    return guarded([&]() -> int {
+    if (!c || !id_bytes) return fail(FRHOT_EINVAL, "null argument");
+    if (world < 1 || world > 256 || rank < 0 || rank >= world)
+        return fail(FRHOT_EINVAL, "rank %d of %d out of range (1 <= world <= 256)", rank, world);
+    Rccl* r = rccl();
+    if (!r) return fail(FRHOT_ESTATE, "RCCL could not be loaded (%s)", g_rccl_why.c_str());
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->comm) return fail(FRHOT_ESTATE, "the context is rank %d of %d already", c->dist_rank, c->dist_world);
+    DeviceGuard dg(c->device);
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(r, r->comm_init_rank(&comm, world, id, rank));
+    c->comm = comm; c->dist_rank = rank; c->dist_world = world;
+    return FRHOT_OK;
+    });
+}
+
+int frhot_dist_shutdown(frhot_ctx* c) {
+    return guarded([&]() -> int {
+    if (!c) return fail(FRHOT_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dist_release(c);
+    return FRHOT_OK;
+    });
+}
+
+int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local, const int32_t* qkeys_local, int B, int k,
+                             void* scores_dev, void* rows_dev, int64_t row_base) {
+    return guarded([&]() -> int {
+    if (!g || !q_local || !scores_dev || !rows_dev) return fail(FRHOT_EINVAL, "null argument");
+    frhot_ctx* c = g->ctx;
+    if (B <= 0 || k <= 0 || k > 16) return fail(FRHOT_EINVAL, "B %d / k %d out of range (k <= 16)", B, k);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->comm) return fail(FRHOT_ESTATE, "the context has joined no communicator (frhot_dist_init)");
+    Rccl* r = rccl();
+    if (!r) return fail(FRHOT_ESTATE, "RCCL could not be loaded (%s)", g_rccl_why.c_str());
+    DeviceGuard dg(c->device);
+    const int P = c->dist_world;
+    const size_t n = (size_t)P * B, nk = n * k;
+    if (n > (size_t)1 << 20) return fail(FRHOT_ECAPACITY, "%d ranks x %d queries: more than 2^20 queries in one step", P, B);
+    // A shard's answer is one block of int64 words: its rows [n,k], then its scores (float32 [n,k],
+    // four bytes of padding after an odd count), the layout the merge reads in place.
+    const size_t words = nk + (nk + 1) / 2;
+    int rc = grow(&c->xq, &c->xq_cap, n * g->D * 2);
+    if (!rc && qkeys_local) rc = grow((void**)&c->xk, &c->xk_cap, n * 4);
+    if (!rc) rc = grow((void**)&c->xblk, &c->xblk_cap, (size_t)(P + 1) * words * 8);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    int64_t* const mine = c->xblk;
+    int64_t* const all = c->xblk + words;
+    RCCL_TRY(r, r->all_gather(q_local, c->xq, (size_t)B * g->D, ncclFloat16, comm, s));
+    if (qkeys_local) RCCL_TRY(r, r->all_gather(qkeys_local, c->xk, (size_t)B, ncclInt32, comm, s));
+    rc = search_enqueue(g, c->xq, qkeys_local ? c->xk : nullptr, (int)n, k, (float*)(mine + nk), mine, row_base);
+    if (rc) return rc;
+    RCCL_TRY(r, r->all_gather(mine, all, words, ncclInt64, comm, s));
+    HIP_TRY(launch_topk_final((const float*)(all + nk), all, P, k, (int)n, k, 0, (float*)scores_dev, (int64_t*)rows_dev, s,
+                              nullptr, nullptr, (long)(words * 2), (long)words));
     return FRHOT_OK;
     });
 }

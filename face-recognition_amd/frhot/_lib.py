@@ -49,6 +49,10 @@ SIGNATURES = {
     "frhot_search_dev_keyed": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_merge_topk_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "frhot_merge_topk_packed_dev": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "frhot_dist_unique_id": (C.c_int, [_p]),
+    "frhot_dist_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
+    "frhot_dist_shutdown": (C.c_int, [_p]),
+    "frhot_search_sharded_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),
     "frhot_crop_sharpness": (C.c_int, [_p, _u8pp, _i32p, _i32p, C.c_int, _i64p]),

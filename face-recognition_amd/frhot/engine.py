@@ -162,6 +162,23 @@ class Context:
         check(self._lib.frhot_merge_topk_packed_dev(self._h, C.c_void_p(packed_dev), shard_stride_bytes, p, bq, k,
                                                     C.c_void_p(out_s_dev), C.c_void_p(out_r_dev)))
 
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        """128 bytes that rank 0 makes and every rank passes to dist_init (carried by the host's own means)."""
+        buf = C.create_string_buffer(128)
+        check(_lib.load().frhot_dist_unique_id(buf))
+        return buf.raw
+
+    def dist_init(self, rank: int, world: int, unique_id: bytes):
+        """Join a communicator of `world` ranks (collective): the exchange of Gallery.search_sharded_dev
+        then runs inside the library over RCCL."""
+        if len(unique_id) != 128:
+            raise ValueError("the id is 128 bytes")
+        check(self._lib.frhot_dist_init(self._h, rank, world, C.c_char_p(unique_id)))
+
+    def dist_shutdown(self):
+        check(self._lib.frhot_dist_shutdown(self._h))
+
     def recognise(self, gallery: "Gallery", images, qkeys=None, k: int = 5, gamma: bool = False, flip: bool = True,
                   want_embeddings: bool = False, want_sharpness: bool = False):
         """Fused embed -> search.  Returns (scores [n,k], rows [n,k], embeddings or None), and with
@@ -316,6 +333,14 @@ class Gallery:
         """search_dev without any allocation: the scan's scratch is a static device array."""
         check(self._lib.frhot_search_dev_static(self._h, C.c_void_p(q_f16_dev), C.c_void_p(qkeys_dev or 0), bq, k,
                                                 C.c_void_p(scores_dev), C.c_void_p(rows_dev), row_base))
+
+    def search_sharded_dev(self, q_local_f16_dev: int, qkeys_local_dev: int | None, b: int, k: int, scores_dev: int,
+                           rows_dev: int, row_base: int = 0):
+        """This rank's b queries in, every rank's answers out ([world*b, k], rank-major, global rows):
+        gather / scan of this shard / gather / merge, enqueued on the context stream (collective)."""
+        check(self._lib.frhot_search_sharded_dev(self._h, C.c_void_p(q_local_f16_dev),
+                                                 C.c_void_p(qkeys_local_dev or 0), b, k, C.c_void_p(scores_dev),
+                                                 C.c_void_p(rows_dev), row_base))
 
 
 __all__ = ["Context", "Gallery", "EMBED_DIM", "KEY_ANY"]

@@ -218,7 +218,7 @@ int frhot_search_dev_keyed(frhot_gallery* g, const void* q_f16_dev, const int32_
  * frhot_search_dev for callers that cannot allocate (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments, same answer bit for bit; the scan's per-block candidate lists and score
- * bounds live in a static device array of the library (about 4.5 MB on every GPU the library
+ * bounds live in a static device array of the library (about 5 MB on every GPU the library
  * runs on, held until the process ends) instead of buffers the gallery grows on demand, and
  * the call makes no hipMalloc / hipFree / allocating library call.  Limits: walkers x queries x
  * list length <= 327,680 entries and at most 8192 queries, i.e. up to 8192 queries of top-5,
@@ -252,6 +252,37 @@ int frhot_merge_topk_dev(frhot_ctx* ctx, const void* scores_dev, const void* row
  */
 int frhot_merge_topk_packed_dev(frhot_ctx* ctx, const void* packed_dev, int64_t shard_stride_bytes,
                                 int P, int Bq, int k, void* out_scores_dev, void* out_rows_dev);
+
+/*
+ * The row-sharded search as ONE call per rank, with the exchange inside the library (RCCL
+ * over xGMI): for hosts that are not Python and have no torch.distributed.  One process
+ * per GPU, one context per process; rank r's gallery holds the global rows
+ * [row_base, row_base + its rows).  Replaces: nothing in the reference (one Qdrant node,
+ * qdrant_database_FE/app.py:316-337 searches it whole); these are the gather / scan /
+ * gather / merge steps of the search over a gallery too large or too hot for one GPU.
+ *
+ * frhot_dist_unique_id: 128 bytes that rank 0 makes and hands to every rank by any means
+ *   of the host's own (a file, a socket, its job launcher).
+ * frhot_dist_init: joins the context to a communicator of `world` ranks (collective: every
+ *   rank calls it with the same id).  RCCL is loaded at this call (dlopen of the name in
+ *   FRHOT_RCCL_LIB, else librccl.so.1 as the process already holds it or as the loader finds
+ *   it); FRHOT_ESTATE if it cannot be loaded or the context has joined already.
+ * frhot_dist_shutdown: leaves the communicator (collective); frhot_ctx_destroy does the
+ *   same for a context that still holds one.
+ * frhot_search_sharded_dev: every rank passes ITS B queries (fp16 unit rows on the device,
+ *   and keys or NULL: all ranks pass keys or none does) and receives the global top-k of all
+ *   world * B queries, rank-major: scores_dev [world*B, k] float32, rows_dev [world*B, k]
+ *   int64 global rows.  Collective: same B and k on every rank.  Enqueues on the context
+ *   stream (two all-gathers of a few hundred KB, the shard's scan between them, the merge)
+ *   and returns without waiting.  The answer is the one frhot_search_dev gives on the whole
+ *   gallery in one piece, bit for bit, ties included.  Its exchange buffers grow on demand
+ *   at the call (hipMalloc), like a gallery's.  world = 1 runs the same steps.
+ */
+int frhot_dist_unique_id(void* id_out_128_bytes);
+int frhot_dist_init(frhot_ctx* ctx, int rank, int world, const void* id_128_bytes);
+int frhot_dist_shutdown(frhot_ctx* ctx);
+int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, const int32_t* qkeys_local_dev,
+                             int B, int k, void* scores_dev, void* rows_dev, int64_t row_base);
 
 /*
  * Fused embed -> search on one GPU: B host crops, qkeys[B] (or NULL), top-k

@@ -1090,6 +1090,54 @@ def test_sharded_search_exchange_path_on_rccl(gpu_ctx):
     assert np.abs(got_s - want_s).max() <= 2e-3        # the host call normalises float32 queries; here they arrive as fp16
 
 
+@pytest.mark.parametrize("with_keys", [False, True])
+def test_search_sharded_dev_inside_the_library(gpu_ctx, with_keys):
+    """frhot_search_sharded_dev (RCCL bound by the library itself, no torch.distributed) in a
+    communicator of one rank: both all-gathers, the shard scan with a row base and the merge run;
+    the answer equals frhot_search_dev's on the same fp16 queries bit for bit.  Twice in a row, the
+    second call with fewer queries (the exchange buffers are reused)."""
+    import torch
+
+    from frhot import synth
+    from frhot.engine import Context, Gallery
+    dev = torch.device("cuda", 0)
+    n, d, k, base = 60_000, 512, 5, 3_000_000
+    g = synth.unit_gallery(seed=14, n=n, d=d)
+    keys = (np.arange(n) % 37).astype(np.int32)
+    gal = Gallery(gpu_ctx, d, n)
+    gal.upsert(g, keys, np.arange(n))
+    gpu_ctx.dist_init(0, 1, Context.dist_unique_id())
+    try:
+        with pytest.raises(Exception):
+            gpu_ctx.dist_init(0, 1, Context.dist_unique_id())       # joined already
+        for b in (23, 7):
+            q = synth.planted_queries(np.random.default_rng(b), g[100:100 + b], 0.8)
+            q16 = torch.from_numpy(q.astype(np.float16)).to(dev)
+            qk = torch.from_numpy(keys[100:100 + b].copy()).to(dev) if with_keys else None
+            want_s = torch.empty((b, k), dtype=torch.float32, device=dev)
+            want_r = torch.empty((b, k), dtype=torch.int64, device=dev)
+            got_s, got_r = torch.full_like(want_s, 7.0), torch.full_like(want_r, -7)
+            torch.cuda.synchronize()
+            gal.search_dev(q16.data_ptr(), qk.data_ptr() if with_keys else None, b, k, want_s.data_ptr(),
+                           want_r.data_ptr(), base)
+            gal.search_sharded_dev(q16.data_ptr(), qk.data_ptr() if with_keys else None, b, k, got_s.data_ptr(),
+                                   got_r.data_ptr(), base)
+            gpu_ctx.sync()
+            assert torch.equal(got_r, want_r) and torch.equal(got_s, want_s)
+            assert int(got_r[:, 0].min()) >= base
+            if with_keys:
+                assert np.array_equal((got_r.cpu().numpy() - base) % 37, np.repeat(keys[100:100 + b, None], k, 1))
+    finally:
+        gpu_ctx.dist_shutdown()
+        gal.close()
+    with pytest.raises(Exception):
+        gal2 = Gallery(gpu_ctx, d, 16)
+        try:
+            gal2.search_sharded_dev(1, None, 1, 1, 1, 1)        # no communicator any more: refused before any use
+        finally:
+            gal2.close()
+
+
 def test_sharded_service_one_rank_equals_single_service(gpu_ctx):
     """ShardedGalleryService over the HIP backend with ONE rank (no process group: the collectives
     fall away, everything else runs: global-row placement, the device-pointer embed, the search by key
