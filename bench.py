@@ -357,11 +357,26 @@ def main():
 
         def merge(s_all, r_all, out_s, out_r):
             # the gathered blocks are merged where the all-gather left them
-            ctx.merge_topk_packed_dev(r_all.data_ptr(), sharded.block_bytes, P, P * B, K, out_s.data_ptr(),
+            ctx.merge_topk_packed_dev(r_all.data_ptr(), exchange.block_bytes, P, P * B, K, out_s.data_ptr(),
                                       out_r.data_ptr())
 
-        sharded = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse,
-                                drain_before_exchange=share_gpu)
+        exchange = ShardedSearch(P, B, D, K, dev, search_local, merge, always_exchange=rehearse,
+                                 drain_before_exchange=share_gpu)
+        sharded = exchange
+        # FRHOT_BENCH_NATIVE_EXCHANGE=1: the same step through frhot_search_sharded_dev, the exchange inside
+        # the library over its own RCCL communicator (the id travels over the torch group).  Opt-in: the
+        # default line stays on the path the multi-GPU runs of earlier rounds measured.
+        native = (P > 1 or rehearse) and bool(os.environ.get("FRHOT_BENCH_NATIVE_EXCHANGE")) and not share_gpu
+        if native:
+            box = [Context.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.dist_init(rank, P, box[0])
+            nat_s = torch.empty((P * B, K), dtype=torch.float32, device=dev)
+            nat_r = torch.empty((P * B, K), dtype=torch.int64, device=dev)
+
+            def sharded(q):
+                gal.search_sharded_dev(q.data_ptr(), None, B, K, nat_s.data_ptr(), nat_r.data_ptr(), row_base)
+                return nat_s, nat_r
         last = {}
 
         def step():
@@ -413,6 +428,11 @@ def main():
         gs, gr = sharded(every[src * B:(src + 1) * B].contiguous())
         torch.cuda.synchronize()
         gs, gr = gs.cpu().numpy(), gr.cpu().numpy()
+        native_same = None
+        if native:          # the library's exchange against torch.distributed's on the same queries, bit for bit
+            ts, tr = exchange(every[src * B:(src + 1) * B].contiguous())
+            torch.cuda.synchronize()
+            native_same = bool(np.array_equal(tr.cpu().numpy(), gr) and np.array_equal(ts.cpu().numpy(), gs))
         gate_ok = True
         for r in range(P):                      # the answer holds every rank's queries: check them all
             asked_rank = (r + 1) % P
@@ -517,7 +537,9 @@ def main():
                 "config": {"workload": (f"embed {B} crops/GPU (gamma LUT + VGG-Face + L2) + exact cosine top-{K} vs "
                                         f"{args.gallery_rows}x{D} fp16 gallery row-sharded over {P} GPU(s)"),
                            "batch_per_gpu": B, "gallery_rows": args.gallery_rows, "dim": D, "k": K,
-                           "parallelism": f"dp{P}+rowshard{P}"},
+                           "parallelism": f"dp{P}+rowshard{P}",
+                           "exchange": "frhot_search_sharded_dev (RCCL inside the library)" if native
+                           else "torch.distributed all-gathers + frhot_merge_topk_packed_dev"},
                 "roofline": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": traffic_src,
@@ -532,6 +554,8 @@ def main():
                 "stages_ms": stages, "result_sane": sane,
                 "gates": {"exchange_top1_is_the_asked_row": gate_ok},
             }
+            if native_same is not None:
+                line["gates"]["library_exchange_equals_torch_exchange"] = native_same
             if host_leg is not None:
                 line["value_pcie_inclusive"] = host_leg["value"]
                 line["pcie_inclusive"] = host_leg
