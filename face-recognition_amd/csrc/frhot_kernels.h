@@ -42,6 +42,11 @@ hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, vo
 // `dump`: >= 1 KiB of device scratch (dead lanes of a partial tile store there).
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias,
                           void* y, void* dump, int B, hipStream_t s);
+// Prototype (libraries built with -DFR_WINOGRAD=1 only; the micro-benchmark): the same convolution
+// by Winograd F(2x2,3x3) for the layers that have such a form (others: hipErrorInvalidValue).  U = launch_wino_weights(w): 16 * cout * cin fp16, made once per layer.
+hipError_t launch_wino_weights(const void* w, void* U, int cin, int cout, hipStream_t s);
+hipError_t launch_conv3x3_wino(const ConvLayerDesc& d, const void* x, const void* U, const float* bias, void* y,
+                               int B, hipStream_t s);
 // Split-K GEMM partial[z][m][n] = sum_{k in slice z} x[m][k] * w[n][k]; M rows of x,
 // N rows of w, K multiple of 64*splitk, N multiple of 128.
 hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M, int N, int K,

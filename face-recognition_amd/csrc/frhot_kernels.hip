@@ -23,6 +23,12 @@
 #ifndef FR_LOOP_MIN_K
 #define FR_LOOP_MIN_K 10
 #endif
+#ifndef FR_WINOGRAD
+#define FR_WINOGRAD 0   // 1: build the Winograd prototype of the 28 x 28 x 512 layer (micro-benchmark only)
+#endif
+#ifndef FR_WABL
+#define FR_WABL 0   // ablation builds of the Winograd kernel (wrong results, timing only)
+#endif
 #ifndef FR_DBG
 #define FR_DBG 0   // diagnostic builds only: 1 no conv stores, 2 no patch DMA, 4 no MFMA, 8 in-kernel stamps (patch conv)
 #endif
@@ -35,7 +41,7 @@ namespace frhot {
 __device__ unsigned long long g_scan_stamp[256 * 16];
 __device__ unsigned long long g_scan_tiles[256 * 20];     // wave 0: clock at the end of each of the first 20 tiles
 #endif
-#if FR_DBG & (8 | 32 | 64)
+#if FR_DBG & (8 | 32 | 64 | 256)
 __device__ unsigned long long g_stamp[64];
 #define FR_STAMP(var)                                                                        \
     do {                                                                                     \
@@ -2935,6 +2941,439 @@ __global__ __launch_bounds__(64) void topk_final_kernel(const float* __restrict_
     }
 }
 
+#if FR_WINOGRAD
+// ------------------------------------------------------ Winograd F(2x2, 3x3) ---
+// PROTOTYPE, not part of the library (built with -DFR_WINOGRAD=1 into scripts/kbench only).
+// Measured on conv4_2 at 256 faces it runs level with the direct kernel (0.84 against 0.83 ms)
+// with outputs within 7.5e-4 of the layer maximum; with all global traffic removed from its
+// chunk loop it would take 0.59 ms.  Per 256 MFMAs it moves 96 KiB from L2 (64 KiB of U, 32 KiB
+// of patch) and about 220 KiB through LDS, against 32 KiB and 96 KiB for the direct kernel's
+// same output: on this part the 2.25 x saved MFMAs are paid for in L2 and LDS bandwidth.
+// 3x3 convolution with 2.25 x fewer multiplies: a 4x4 input window d of one channel becomes
+// V = Bt d B (16 values), a 3x3 filter g becomes U = G g Gt (16 values, made once at model
+// load), the 16 products are summed over the input channels position by position (16
+// independent GEMMs over [tiles] x [Cin] x [Cout]) and a 2x2 output block is At M A.
+//
+// A block item is 64 tile slots (TR rows of HW/2 tiles, rows taken from a flat list over all
+// images) by 64 output channels, all 16 positions, walked in chunks of 32 input channels.
+// Wave w owns positions 2w and 2w+1 for the whole 64 x 64 item (128 accumulator registers).
+//   U   never passes through LDS: every fragment is needed by exactly one wave, and the
+//       weights are stored in fragment order [channel block][chunk][position][16-channel
+//       group][lane][16 B], so a wave's 8 KiB per chunk are eight coalesced loads;
+//   x   the item's input rows of one chunk (4 rows of HW+2 pixels per tile row, 64 B each)
+//       arrive by LDS-DMA; within a 16-pixel piece the even pixels come first, so the four
+//       pixels a group of four neighbouring tiles reads (two apart) lie in one 256-B row;
+//   V   every thread transforms one (tile, 4 channels) window per chunk with packed fp16
+//       adds and writes its 16 values into the V stage [position][tile][32 channels]
+//       (64-B rows, 16-B chunk c at c ^ ((-(tile >> 2)) & 3): conflict-free ds_read_b128
+//       fragments); two V stages, one patch stage.
+// Output transform: wave w first folds its two positions into the two column sums it
+// contributes to, the eight waves' partial sums meet in LDS (one output column at a time:
+// 128 KiB), and every thread finishes 8 channels of one tile: row transform, bias, ReLU,
+// optional 2x2 max (a tile IS a pooling window), one 16-B store per pixel.
+template <int HW>
+struct WinoGeo {
+    static constexpr int TW = HW / 2;
+    static constexpr int TR = 64 / TW < 8 ? 64 / TW : 8;
+    static constexpr int PW = HW + 2;
+    static constexpr int PR = (4 * PW + 15) / 16 * 16;
+    static constexpr int NPIECE = TR * PR / 16;
+    static_assert(TW <= 64 && NPIECE <= 32, "a patch stage is 32 one-KiB pieces");
+};
+
+FR_DEV void wino_lds_read_b64(half4& d, unsigned addr, int off) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(off) : "memory");
+}
+
+template <int OFF>
+FR_DEV void wino_gload(half8& u, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(u) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+
+__global__ __launch_bounds__(256) void wino_weights_kernel(const half_t* __restrict__ w, half_t* __restrict__ U,
+                                                           int cin, int cout) {
+    // w [Cout][3][3][Cin] -> U [Cout/64][Cin/32][16][4][64 lanes][8]: G g Gt in float32, rounded once
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)cout * cin * 2;      // 16 positions x Cout x Cin / 8
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), ns = (int)((idx >> 6) & 3), pos = (int)((idx >> 8) & 15);
+    const long rest = idx >> 12;
+    const int nkc = cin / 32;
+    const int kc = (int)(rest % nkc), nb = (int)(rest / nkc);
+    const int co = nb * 64 + ns * 16 + (lane & 15), ci0 = kc * 32 + 8 * (lane >> 4);
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    const int xi = pos >> 2, nu = pos & 3;
+    half8 o;
+    for (int e = 0; e < 8; ++e) {
+        float acc = 0.f;
+        for (int r = 0; r < 3; ++r)
+            for (int s = 0; s < 3; ++s)
+                acc += Gm[xi][r] * Gm[nu][s] * (float)w[((long)(co * 3 + r) * 3 + s) * cin + ci0 + e];
+        o[e] = (half_t)acc;
+    }
+    *(half8*)(U + idx * 8) = o;
+}
+
+template <int HW, int CIN, int COUT, bool POOL, int OPAD>
+__global__ __launch_bounds__(512) void conv3x3_wino_kernel(const half_t* __restrict__ x,
+                                                           const half_t* __restrict__ U,
+                                                           const float* __restrict__ bias,
+                                                           half_t* __restrict__ y, int batch) {
+    using Geo = WinoGeo<HW>;
+    constexpr int TW = Geo::TW, TR = Geo::TR, PW = Geo::PW, PR = Geo::PR;
+    constexpr int NKC = CIN / 32, NB = COUT / 64, HT = HW / 2;
+    constexpr int VBUF = 65536, PATCH = 2 * VBUF;
+    static_assert(CIN % 64 == 0 && COUT % 64 == 0, "channel tiling");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = lds_offset(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int RT = batch * HT;
+    const int nmb = (RT + TR - 1) / TR;
+    const long nitems = (long)nmb * NB;
+    const int G = gridDim.x;
+    const int wk = xcd_remap(blockIdx.x, G);
+
+    // this thread's transform task: tile slot tm, channels 4*tq .. 4*tq+3 of the chunk
+    const int tm = tid >> 3, tq = tid & 7;
+    const bool tlive = tm < TR * TW;
+    const int trow = tlive ? tm / TW : 0, tcol = tlive ? tm % TW : 0;
+    unsigned paddr[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const int PP = trow * PR + i * PW + 2 * tcol + 2 * jp;     // even; the odd neighbour is 512 B further
+            paddr[i][jp] = lds0 + PATCH + (PP >> 4) * 1024 + ((PP >> 1) & 7) * 64 + (tq >> 1) * 16 + (tq & 1) * 8;
+        }
+    const unsigned vw = lds0 + tm * 64 + ((((tq >> 1) ^ ((0 - (tm >> 2)) & 3))) << 4) + (tq & 1) * 8;
+    const unsigned vr = lds0 + (2 * wave) * 4096 + l15 * 64 + (((g ^ ((0 - (l15 >> 2)) & 3))) << 4);
+
+    float4v acc[2][4][4];       // [position][channel group][tile group]
+    half8 ufr[2][4];
+    half4 d[4][4];
+
+    // Which items a block walks.  The transformed weights of one 64-channel block are 32 * CIN
+    // bytes per position, 16 positions: with COUT = 512 all eight blocks together (8 MiB at
+    // CIN = 512) do not fit an XCD's 4 MiB L2, and every U fragment would come from the Infinity
+    // Cache.  So each XCD serves TWO channel blocks (its quarter of U stays in its L2) and half
+    // of the tile rows; the two items of a tile-row group run side by side on two of its CUs
+    // and share the patch in L2.
+    const int per = G >> 3, xcd = wk / (per > 0 ? per : 1), local = wk % (per > 0 ? per : 1);
+    const bool split = NB == 8 && (G & 7) == 0;
+    const int mbh = (nmb + 1) / 2;
+    const int mb_lo = split ? (xcd >> 2) * mbh : 0;
+    const int mb_hi = split ? (mb_lo + mbh < nmb ? mb_lo + mbh : nmb) : nmb;
+    const long first = split ? local : wk, stride = split ? per : G;
+    const long count = split ? (long)(mb_hi - mb_lo) * 2 : nitems;
+    for (long item = first; item < count; item += stride) {
+        const int mb = split ? mb_lo + (int)(item >> 1) : (int)(item / NB);
+        const int nb = split ? 2 * (xcd & 3) + (int)(item & 1) : (int)(item % NB);
+        const int R0 = mb * TR;
+        unsigned xo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = wave + 8 * i;
+            const int row = lane >> 2, c = lane & 3;
+            const int PP = n * 16 + 2 * (row & 7) + (row >> 3);
+            int r = PP / PR, P = PP % PR;
+            r = r < TR ? r : TR - 1;
+            P = P < 4 * PW ? P : 4 * PW - 1;
+            const int ii = P / PW, px = P % PW;
+            int R = R0 + r;
+            R = R < RT ? R : RT - 1;
+            const int b = R / HT, ty = R % HT;
+            xo[i] = (unsigned)((((b * (HW + 2) + 2 * ty + ii) * PW + px) * CIN) * 2 + c * 16);
+        }
+        // this wave's fragments of chunk 0, position 2*wave: 4 KiB per position, 64 KiB per chunk
+        const char* const ubase = (const char*)U + ((size_t)nb * NKC * 16 + 2 * wave) * 4096;
+        const unsigned uoff = lane * 16;
+
+        auto issue_patch = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned o = xo[i];
+                asm volatile("" : "+v"(o));
+                glds16((const char*)x + kc * 64 + o, smem + PATCH + (wave + 8 * i) * 1024);
+            }
+        };
+        // Written as the instructions themselves: the compiler's own wait for a loaded value would
+        // be vmcnt(0) inside the loop, which also drains the patch DMA issued after it.
+        auto load_u = [&](int kc, int p) __attribute__((always_inline)) {
+            const char* const sb = ubase + (size_t)kc * 65536 + p * 4096;
+            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                         "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                         "global_load_dwordx4 %3, %4, %5 offset:3072"
+                         : "=&v"(ufr[p][0]), "=&v"(ufr[p][1]), "=&v"(ufr[p][2]), "=&v"(ufr[p][3])
+                         : "v"(uoff), "s"(sb) : "memory");
+        };
+        auto load_u1 = [&](int kc, int p, int ns) __attribute__((always_inline)) {
+            const char* const sb = ubase + (size_t)kc * 65536 + p * 4096;
+            if (ns == 0) wino_gload<0>(ufr[p][0], uoff, sb);
+            else if (ns == 1) wino_gload<1024>(ufr[p][1], uoff, sb);
+            else if (ns == 2) wino_gload<2048>(ufr[p][2], uoff, sb);
+            else wino_gload<3072>(ufr[p][3], uoff, sb);
+        };
+        auto wait_u = [&](int p) __attribute__((always_inline)) {       // all but the newest eight vector-memory ops
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(ufr[p][0]), "+v"(ufr[p][1]), "+v"(ufr[p][2]), "+v"(ufr[p][3]) :: "memory");
+        };
+        auto transform_read = [&](int i0 = 0, int i1 = 4) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j & 1) wino_lds_read_b64(d[i][j], paddr[i][j >> 1], 512);
+                    else wino_lds_read_b64(d[i][j], paddr[i][j >> 1], 0);
+                }
+        };
+        auto transform_wait = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]),
+                           "+v"(d[1][2]), "+v"(d[1][3]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[2][2]), "+v"(d[2][3]),
+                           "+v"(d[3][0]), "+v"(d[3][1]), "+v"(d[3][2]), "+v"(d[3][3])
+                         :: "memory");
+        };
+        auto transform_cols = [&](int j0 = 0, int j1 = 4) __attribute__((always_inline)) {       // Bt d, in place
+#pragma unroll
+            for (int j = j0; j < j1; ++j) {
+                const half4 a = d[0][j] - d[2][j], b = d[1][j] + d[2][j], c = d[2][j] - d[1][j], e = d[1][j] - d[3][j];
+                d[0][j] = a; d[1][j] = b; d[2][j] = c; d[3][j] = e;
+            }
+        };
+        auto transform_rows = [&](int i0 = 0, int i1 = 4) __attribute__((always_inline)) {       // (Bt d) B, in place
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const half4 a = d[i][0] - d[i][2], b = d[i][1] + d[i][2], c = d[i][2] - d[i][1], e = d[i][1] - d[i][3];
+                d[i][0] = a; d[i][1] = b; d[i][2] = c; d[i][3] = e;
+            }
+        };
+        auto transform_write = [&](int buf, int i0 = 0, int i1 = 4) __attribute__((always_inline)) {
+            const unsigned a = vw + buf * VBUF;
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(d[i][j]), "n"((i * 4 + j) * 4096) : "memory");
+        };
+        half8 vf[2][4];
+        auto read_v = [&](int buf, int p) __attribute__((always_inline)) {
+            const unsigned a = vr + buf * VBUF + p * 4096;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                         "ds_read_b128 %3, %4 offset:3072"
+                         : "=&v"(vf[p][0]), "=&v"(vf[p][1]), "=&v"(vf[p][2]), "=&v"(vf[p][3]) : "v"(a) : "memory");
+        };
+        auto wait_v = [&](int p, int newer) __attribute__((always_inline)) {     // `newer` LDS ops may stay in flight
+            if (newer == 0)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[p][0]), "+v"(vf[p][1]), "+v"(vf[p][2]), "+v"(vf[p][3]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vf[p][0]), "+v"(vf[p][1]), "+v"(vf[p][2]), "+v"(vf[p][3]) :: "memory");
+        };
+        auto mma = [&](int p, int n0 = 0, int n1 = 4) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ns = n0; ns < n1; ++ns)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+                    acc[p][ns][ms] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufr[p][ns], vf[p][ms], acc[p][ns][ms], 0, 0, 0);
+        };
+        auto fence = [&]() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms) acc[p][ns][ms] = float4v{0.f, 0.f, 0.f, 0.f};
+
+#if FR_DBG & 256
+        unsigned long long ws[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wt0, wt1;
+        FR_STAMP(wt0);
+#define FR_WSTAMP(i) do { FR_STAMP(wt1); ws[i] += wt1 - wt0; wt0 = wt1; } while (0)
+#else
+#define FR_WSTAMP(i) do { } while (0)
+#endif
+        // prologue: chunk 0 transformed into V stage 0, chunk 1's patch and chunk 0's U in flight
+        issue_patch(0);
+        load_u(0, 0);
+        load_u(0, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // the patch
+        __builtin_amdgcn_s_barrier();
+        fence();
+        transform_read();
+        transform_wait();
+        transform_cols();
+        transform_rows();
+        if (tlive) transform_write(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+        issue_patch(NKC > 1 ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ufr[0][0]), "+v"(ufr[0][1]), "+v"(ufr[0][2]), "+v"(ufr[0][3]),
+                     "+v"(ufr[1][0]), "+v"(ufr[1][1]), "+v"(ufr[1][2]), "+v"(ufr[1][3]) :: "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+        // Every chunk issues the same vector-memory operations in the same order (four patch pieces,
+        // then four U fragments for each of the two positions), the last chunks with the chunk index
+        // held at NKC - 1 (what they fetch is never used): the waits below can then always be "all but
+        // the newest eight".
+        FR_WSTAMP(0);
+        // Vector-memory order of a chunk, per wave: four U fragments of position 0 (one behind each
+        // group of four MFMAs that frees its register), after the mid barrier the four patch pieces,
+        // then four U fragments of position 1.  The last chunks fetch with the chunk index held at
+        // NKC - 1 (never used), so the counted waits are the same in every chunk.
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < NKC;
+            const int kn = more ? kc + 1 : kc, kp = kc + 2 < NKC ? kc + 2 : NKC - 1;
+            read_v(buf, 0);
+            if (more && !(FR_WABL & 32)) transform_read(0, 2);
+            fence();
+            if (more) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[0][2]), "+v"(vf[0][3]) :: "memory");
+            else wait_v(0, 0);
+            // in flight at most: position 1's fragments of this chunk
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(ufr[0][0]), "+v"(ufr[0][1]), "+v"(ufr[0][2]), "+v"(ufr[0][3]) :: "memory");
+            fence();
+            FR_WSTAMP(1);
+            if (!(FR_WABL & 16)) mma(0, 0, 1);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 0, 0);
+            if (!(FR_WABL & 16)) mma(0, 1, 2);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 0, 1);
+            if (more && !(FR_WABL & 32)) transform_read(2, 4);
+            read_v(buf, 1);
+            fence();
+            if (!(FR_WABL & 16)) mma(0, 2, 3);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 0, 2);
+            if (!(FR_WABL & 16)) mma(0, 3, 4);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 0, 3);
+            fence();
+            FR_WSTAMP(2);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d[0][0]), "+v"(d[0][1]), "+v"(d[0][2]), "+v"(d[0][3]), "+v"(d[1][0]), "+v"(d[1][1]),
+                           "+v"(d[1][2]), "+v"(d[1][3]), "+v"(d[2][0]), "+v"(d[2][1]), "+v"(d[2][2]), "+v"(d[2][3]),
+                           "+v"(d[3][0]), "+v"(d[3][1]), "+v"(d[3][2]), "+v"(d[3][3]),
+                           "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[1][2]), "+v"(vf[1][3])
+                         :: "memory");
+            fence();
+            FR_WSTAMP(3);
+            __builtin_amdgcn_s_barrier();   // every wave has read the patch: it may be refilled
+            fence();
+            FR_WSTAMP(4);
+            if (!(FR_WABL & 8)) issue_patch(kp);
+            fence();
+            wait_u(1);                      // behind position 1's fragments: four of the next chunk, the patch
+            fence();
+            FR_WSTAMP(5);
+            if (!(FR_WABL & 16)) mma(1, 0, 1);
+            if (more) if (!(FR_WABL & 1)) transform_cols(0, 2);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 1, 0);
+            if (!(FR_WABL & 16)) mma(1, 1, 2);
+            if (more) if (!(FR_WABL & 1)) transform_cols(2, 4);
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 1, 1);
+            if (!(FR_WABL & 16)) mma(1, 2, 3);
+            if (more) { if (!(FR_WABL & 1)) transform_rows(0, 2); if (tlive && !(FR_WABL & 2)) transform_write(buf ^ 1, 0, 2); }
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 1, 2);
+            if (!(FR_WABL & 16)) mma(1, 3, 4);
+            if (more) { if (!(FR_WABL & 1)) transform_rows(2, 4); if (tlive && !(FR_WABL & 2)) transform_write(buf ^ 1, 2, 4); }
+            fence();
+            if (!(FR_WABL & 4)) load_u1(kn, 1, 3);
+            fence();
+            FR_WSTAMP(6);
+            // all but position 1's new fragments: the patch has landed; this wave's V writes are done
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            FR_WSTAMP(7);
+            __builtin_amdgcn_s_barrier();
+            fence();
+            FR_WSTAMP(8);
+        }
+        // the loads of the last chunk land in registers that are free from here on: wait for them
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ufr[0][0]), "+v"(ufr[0][1]), "+v"(ufr[0][2]), "+v"(ufr[0][3]),
+                     "+v"(ufr[1][0]), "+v"(ufr[1][1]), "+v"(ufr[1][2]), "+v"(ufr[1][3]) :: "memory");
+        fence();
+
+        // output transform
+        const int T = tid >> 3, o8 = tid & 7;
+        const int er = T / TW, et = T % TW;
+        const int ER = R0 + er;
+        const bool elive = T < TR * TW && ER < RT;
+        const int eb = elive ? ER / HT : 0, ety = elive ? ER % HT : 0;
+        const float4v b0 = *(const float4v*)(bias + nb * 64 + o8 * 8), b1 = *(const float4v*)(bias + nb * 64 + o8 * 8 + 4);
+        constexpr int HO = POOL ? HT : HW, OW = HO + 2 * OPAD;
+        float pooled[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms) {
+                    const float4v a0 = acc[0][ns][ms], a1 = acc[1][ns][ms];
+                    float4v z;
+                    if ((wave & 1) == 0) z = j == 0 ? a0 + a1 : a1;
+                    else z = j == 0 ? a0 : -a0 - a1;
+                    *(float4v*)(smem + wave * 16384 + (ms * 16 + l15) * 256 + (((ns * 4 + g) ^ l15) << 4)) = z;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float zs[4][8];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int ch = ((2 * o8 + hh) ^ (T & 15)) << 4;
+                    const float4v u0 = *(const float4v*)(smem + (2 * xi) * 16384 + T * 256 + ch);
+                    const float4v u1 = *(const float4v*)(smem + (2 * xi + 1) * 16384 + T * 256 + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zs[xi][hh * 4 + e] = u0[e] + u1[e];
+                }
+            }
+            half8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float bb = e < 4 ? b0[e] : b1[e - 4];
+                const float y0 = fmaxf(zs[0][e] + zs[1][e] + zs[2][e] + bb, 0.f);
+                const float y1 = fmaxf(zs[1][e] - zs[2][e] - zs[3][e] + bb, 0.f);
+                if (POOL) {
+                    const float m = fmaxf(y0, y1);
+                    pooled[e] = j == 0 ? m : fmaxf(pooled[e], m);
+                    o0[e] = (half_t)pooled[e];
+                } else {
+                    o0[e] = (half_t)y0;
+                    o1[e] = (half_t)y1;
+                }
+            }
+            if (elive) {
+                if (POOL) {
+                    if (j == 1)
+                        *(half8*)(y + (((long)eb * OW + ety + OPAD) * OW + et + OPAD) * COUT + nb * 64 + o8 * 8) = o0;
+                } else {
+                    half_t* const p0 = y + (((long)eb * OW + 2 * ety + OPAD) * OW + 2 * et + j + OPAD) * COUT + nb * 64 + o8 * 8;
+                    *(half8*)p0 = o0;
+                    *(half8*)(p0 + (long)OW * COUT) = o1;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        FR_WSTAMP(9);
+#if FR_DBG & 256
+        if (blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == 5)) {
+            ws[10] += 1;
+            for (int i = 0; i < 11; ++i) g_stamp[(wave ? 16 : 0) + i] += ws[i];
+        }
+#endif
+    }
+}
+
+#endif  // FR_WINOGRAD
+
 // ---------------------------------------------------------------- launch ---
 #define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -3019,6 +3458,53 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
 #undef FR_CONV
     return hipErrorInvalidValue;
 }
+
+#if FR_WINOGRAD
+template <int HW, int CIN, int COUT, bool POOL, int OPAD>
+static hipError_t launch_wino_inst(const void* x, const void* U, const float* bias, void* y, int B, hipStream_t s,
+                                   bool set_attr_only) {
+    auto kern = conv3x3_wino_kernel<HW, CIN, COUT, POOL, OPAD>;
+    constexpr int lds = 2 * 65536 + 32768;
+    if (set_attr_only)
+        return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if ((unsigned long long)B * (HW + 2) * (HW + 2) * CIN * 2ull >= (1ull << 31)) return hipErrorInvalidValue;
+    using Geo = WinoGeo<HW>;
+    const long items = (((long)B * (HW / 2) + Geo::TR - 1) / Geo::TR) * (COUT / 64);
+    long grid = 256;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)U, bias,
+                       (half_t*)y, B);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+static hipError_t wino_dispatch(const ConvLayerDesc& d, const void* x, const void* U, const float* bias, void* y, int B,
+                                hipStream_t s, bool attr) {
+#define FR_WINO(HW, CIN, COUT, POOL, OPAD)                                                          \
+    if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == OPAD) \
+        return launch_wino_inst<HW, CIN, COUT, POOL, OPAD>(x, U, bias, y, B, s, attr);
+    FR_WINO(28, 512, 512, false, 1)
+#undef FR_WINO
+    return hipErrorInvalidValue;
+}
+
+// U: 16 * cout * cin fp16 (see wino_weights_kernel)
+hipError_t launch_wino_weights(const void* w, void* U, int cin, int cout, hipStream_t s) {
+    if (!w || !U || cin % 32 || cout % 64) return hipErrorInvalidValue;
+    const long total = (long)cout * cin * 2;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t*)w,
+                       (half_t*)U, cin, cout);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_conv3x3_wino(const ConvLayerDesc& d, const void* x, const void* U, const float* bias, void* y, int B,
+                               hipStream_t s) {
+    if (B <= 0 || !x || !U || !bias || !y) return hipErrorInvalidValue;
+    return wino_dispatch(d, x, U, bias, y, B, s, false);
+}
+
+#endif  // FR_WINOGRAD
 
 // `dump` is >= 1 KiB of scratch that dead lanes of a partial tile store to.
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias, void* y,
@@ -3167,6 +3653,13 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStr
     return hipSuccess;
 }
 
+#if FR_DBG & 256
+hipError_t debug_stamps_read(unsigned long long* out64) { return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamp), 64 * 8); }
+hipError_t debug_stamps_clear() {
+    unsigned long long z[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z);
+}
+#endif
 #if FR_DBG & 64
 hipError_t scan_debug_stamps(unsigned long long* out) {      // 256 x 16 values of the last scan launch
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scan_stamp), sizeof(unsigned long long) * 256 * 16);
@@ -3493,6 +3986,10 @@ hipError_t kernels_init() {
     for (const auto& d : layers) {
         hipError_t e = conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
         if (e != hipSuccess) return e;
+#if FR_WINOGRAD
+        e = wino_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
+        if (e != hipSuccess && e != hipErrorInvalidValue) return e;      // invalid value: no Winograd form of this layer
+#endif
     }
     hipError_t e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);

@@ -17,6 +17,9 @@ using namespace frhot;
 #if FR_DBG & (8 | 32)
 namespace frhot { extern __device__ unsigned long long g_stamp[64]; }
 #endif
+#if FR_DBG & 256
+namespace frhot { hipError_t debug_stamps_read(unsigned long long* out64); hipError_t debug_stamps_clear(); }
+#endif
 #if FR_DBG & 64
 namespace frhot { hipError_t scan_debug_stamps(unsigned long long* out); hipError_t scan_debug_tiles(unsigned long long* out); }
 #include <algorithm>
@@ -77,6 +80,94 @@ static float time_ms(F&& f, int warm, int iters, hipStream_t s) {
     CK(hipEventDestroy(b));
     return ms / iters;
 }
+
+#if FR_WINOGRAD
+// Winograd form of a layer against the direct kernel: same input, outputs compared, both timed.
+static void bench_wino(int B) {
+    static const ConvLayerDesc L[] = {
+        {56, 256, 256, 0, 1}, {56, 256, 256, 1, 1}, {28, 256, 512, 0, 1}, {28, 512, 512, 0, 1},
+        {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
+    };
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    void* dump;
+    CK(hipMalloc(&dump, 4096));
+    for (const ConvLayerDesc& d : L) {
+        const size_t xin = (size_t)B * (d.hw + 2) * (d.hw + 2) * d.cin;
+        const int ho = d.pool ? d.hw / 2 : d.hw;
+        const size_t yout = (size_t)B * (ho + 2 * d.opad) * (ho + 2 * d.opad) * d.cout;
+        void* x = dev_random_f16(xin, 1.0f, 10);
+        void* w = dev_random_f16((size_t)d.cout * 9 * d.cin, 0.05f, 40);
+        std::vector<float> hb(d.cout);
+        for (int i = 0; i < d.cout; ++i) hb[i] = 0.01f * (float)((i * 37) % 21 - 10);
+        float* bias;
+        CK(hipMalloc((void**)&bias, d.cout * 4));
+        CK(hipMemcpy(bias, hb.data(), d.cout * 4, hipMemcpyHostToDevice));
+        void *y0, *y1, *U;
+        CK(hipMalloc(&y0, yout * 2));
+        CK(hipMalloc(&y1, yout * 2));
+        CK(hipMalloc(&U, (size_t)16 * d.cout * d.cin * 2));
+        CK(hipMemset(y0, 0, yout * 2));
+        CK(hipMemset(y1, 0, yout * 2));
+        CK(launch_wino_weights(w, U, d.cin, d.cout, s));
+        hipError_t e = launch_conv3x3_wino(d, x, U, bias, y1, B, s);
+        if (e == hipErrorInvalidValue) {
+            printf("hw %d cin %d cout %d pool %d: no Winograd form\n", d.hw, d.cin, d.cout, d.pool);
+        } else {
+            CK(e);
+            CK(launch_conv3x3(d, x, w, bias, y0, dump, B, s));
+            CK(hipStreamSynchronize(s));
+            std::vector<uint16_t> h0(yout), h1(yout);
+            CK(hipMemcpy(h0.data(), y0, yout * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h1.data(), y1, yout * 2, hipMemcpyDeviceToHost));
+            double mx = 0, md = 0, sd = 0;
+            size_t bad = 0, nz = 0;
+            for (size_t i = 0; i < yout; ++i) {
+                _Float16 a, b;
+                memcpy(&a, &h0[i], 2);
+                memcpy(&b, &h1[i], 2);
+                const double fa = (double)a, fb = (double)b, df = fabs(fa - fb);
+                if (!(df == df)) ++bad;
+                if (fabs(fa) > mx) mx = fabs(fa);
+                if (df > md) md = df;
+                sd += df;
+                nz += fa != 0;
+            }
+            const float t0 = time_ms([&] { CK(launch_conv3x3(d, x, w, bias, y0, dump, B, s)); }, 3, 40, s);
+#if FR_DBG & 256
+            {
+                CK(frhot::debug_stamps_clear());
+            }
+#endif
+            const float t1 = time_ms([&] { CK(launch_conv3x3_wino(d, x, U, bias, y1, B, s)); }, 3, 40, s);
+#if FR_DBG & 256
+            {
+                unsigned long long st[64];
+                CK(frhot::debug_stamps_read(st));
+                static const char* nm[] = {"prologue", "V0/patch issue+wait", "mma0", "wait patch+V1", "barrier B2", "dma issue+wait U1",
+                                           "mma1+transform", "end wait", "barrier B1", "epilogue"};
+                for (int wv = 0; wv < 2; ++wv) {
+                    const double n = (double)st[wv * 16 + 10];
+                    printf("   wave %d, cycles per item (%.0f items):", wv ? 5 : 0, n);
+                    double tot = 0;
+                    for (int i = 0; i < 10; ++i) { printf("  %s %.0f", nm[i], st[wv * 16 + i] / n); tot += st[wv * 16 + i] / n; }
+                    printf("  total %.0f\n", tot);
+                }
+            }
+#endif
+            const double fl = 2.0 * B * d.hw * d.hw * 9.0 * d.cin * d.cout;
+            printf("hw %3d cin %3d cout %3d pool %d: direct %7.3f ms (%6.1f TF)  winograd %7.3f ms (%6.1f TF-equivalent)  "
+                   "max |diff| %.4g of max %.4g (%.2e), mean |diff| %.3g, nonzero %.2f, NaN %zu\n",
+                   d.hw, d.cin, d.cout, d.pool, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, md, mx, md / (mx > 0 ? mx : 1),
+                   sd / yout, (double)nz / yout, bad);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(y0)); CK(hipFree(y1)); CK(hipFree(U));
+    }
+    CK(hipFree(dump));
+    CK(hipStreamDestroy(s));
+}
+
+#endif  // FR_WINOGRAD
 
 static void bench_conv(int B) {
     static const ConvLayerDesc L[] = {
@@ -311,6 +402,9 @@ int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     CK(kernels_init());
     if (!strcmp(what, "conv") || !strcmp(what, "all")) bench_conv(argc > 2 ? atoi(argv[2]) : 256);
+#if FR_WINOGRAD
+    if (!strcmp(what, "wino")) bench_wino(argc > 2 ? atoi(argv[2]) : 256);
+#endif
     if (!strcmp(what, "scan") || !strcmp(what, "all")) bench_scan();
     return 0;
 }
