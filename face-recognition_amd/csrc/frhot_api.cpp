@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <system_error>
@@ -1776,6 +1777,404 @@ int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
         }
         ms5[i] = n > 0 ? (float)(sum / (double)n) : 0.f;
     }
+    return FRHOT_OK;
+    });
+}
+
+}  // extern "C"
+
+// ---- face detector -------------------------------------------------------------------------
+// The network of DeepFace's "yolov8" backend (app/src/utils/legacy.py:60-65,80-86 reach it through
+// DeepFace.extract_faces): YOLOv8n-pose layout with one class and five keypoints on a 640 x 640
+// letterboxed frame.  The graph is fixed, so it is written out here as a list of launches over
+// NHWC fp16 tensors; a concatenation is a tensor that two producers fill by channel slices.
+struct DetTensor { _Float16* p = nullptr; int h = 0, w = 0, c = 0; };
+struct DetSlice { const DetTensor* t; int c0, c; };
+
+struct DetLayer { void* w = nullptr; float* b = nullptr; int k = 0, cin = 0, cout = 0; };   // cin / cout as stored (padded to 16)
+
+struct frhot_detector {
+    frhot_ctx* ctx = nullptr;
+    int max_batch = 0;
+    std::unordered_map<std::string, DetLayer> layers;
+    std::vector<void*> owned;                       // every device allocation of the detector
+    std::unordered_map<std::string, DetTensor> t;   // named tensors (also what frhot_det_debug_read serves)
+    DetImageMeta* meta_dev = nullptr;
+    uint8_t* img_dev = nullptr; size_t img_cap = 0;
+    uint8_t* img_pin = nullptr; size_t img_pin_cap = 0;
+    DetCand* cand_dev = nullptr; int* count_dev = nullptr;
+    DetCand* cand_pin = nullptr; int* count_pin = nullptr;
+    static constexpr int kCap = 2048;               // candidates kept per image before suppression
+};
+
+namespace {
+
+int det_alloc(frhot_detector* d, void** p, size_t n) {
+    HIP_TRY(hipMalloc(p, n));
+    d->owned.push_back(*p);
+    return FRHOT_OK;
+}
+
+int det_tensor(frhot_detector* d, const char* name, int h, int w, int c) {
+    DetTensor t; t.h = h; t.w = w; t.c = c;
+    const int rc = det_alloc(d, (void**)&t.p, (size_t)d->max_batch * h * w * c * 2);
+    if (rc) return rc;
+    d->t[name] = t;
+    return FRHOT_OK;
+}
+
+// One convolution of the blob ("<name>.w" fp16 [cout][k][k][cin], "<name>.b" fp32) with its channel
+// counts padded to multiples of 16 by zeros (the first layer's 3 inputs, the heads' 1 and 15 outputs).
+int det_load_layer(frhot_detector* d, const uint8_t* blob, size_t nbytes, const char* name, int k, int cin, int cout) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "%s.w", name);
+    const BlobEntry* ew = blob_find(blob, nbytes, nm);
+    if (!ew || ew->dtype != 0 || ew->nbytes != (uint64_t)cout * k * k * cin * 2)
+        return fail(FRHOT_EINVAL, "detector blob: bad or missing %s", nm);
+    snprintf(nm, sizeof nm, "%s.b", name);
+    const BlobEntry* eb = blob_find(blob, nbytes, nm);
+    if (!eb || eb->dtype != 1 || eb->nbytes != (uint64_t)cout * 4) return fail(FRHOT_EINVAL, "detector blob: bad or missing %s", nm);
+    const int cip = (cin + 15) / 16 * 16, cop = (cout + 15) / 16 * 16;
+    std::vector<uint16_t> w((size_t)cop * k * k * cip, 0);
+    const uint16_t* src = (const uint16_t*)(blob + ew->offset);
+    for (int n = 0; n < cout; ++n)
+        for (int t = 0; t < k * k; ++t)
+            memcpy(&w[((size_t)n * k * k + t) * cip], &src[((size_t)n * k * k + t) * cin], (size_t)cin * 2);
+    std::vector<float> b(cop, 0.f);
+    memcpy(b.data(), blob + eb->offset, (size_t)cout * 4);
+    DetLayer L; L.k = k; L.cin = cip; L.cout = cop;
+    int rc = det_alloc(d, &L.w, w.size() * 2);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(L.w, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    rc = det_alloc(d, (void**)&L.b, b.size() * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(L.b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    d->layers[name] = L;
+    return FRHOT_OK;
+}
+
+struct DetRun {
+    frhot_detector* d; int B; hipStream_t s;
+    DetSlice all(const char* name) const { const DetTensor& t = d->t.at(name); return DetSlice{&t, 0, t.c}; }
+    DetSlice part(const char* name, int c0, int c) const { return DetSlice{&d->t.at(name), c0, c}; }
+    int conv(const char* layer, DetSlice in, DetSlice out, int stride, bool act, const DetSlice* res = nullptr) const {
+        const DetLayer& L = d->layers.at(layer);
+        if (L.cin != in.c || L.cout != out.c) return fail(FRHOT_ESTATE, "detector graph: %s is %d -> %d, wired %d -> %d", layer, L.cin, L.cout, in.c, out.c);
+        DetConv c{};
+        c.x = in.t->p; c.H = in.t->h; c.W = in.t->w; c.xc = in.t->c; c.xc0 = in.c0; c.cin = in.c;
+        c.w = (const _Float16*)L.w; c.b = L.b;
+        c.y = out.t->p; c.Ho = out.t->h; c.Wo = out.t->w; c.yc = out.t->c; c.yc0 = out.c0; c.cout = out.c;
+        if (res) { c.r = res->t->p; c.rc = res->t->c; c.rc0 = res->c0; }
+        c.k = L.k; c.stride = stride; c.act = act ? 1 : 0;
+        if ((in.t->h + stride - 1) / stride != out.t->h || (in.t->w + stride - 1) / stride != out.t->w)
+            return fail(FRHOT_ESTATE, "detector graph: %s maps %dx%d to %dx%d at stride %d", layer, in.t->h, in.t->w, out.t->h, out.t->w, stride);
+        HIP_TRY(launch_det_conv(c, B, s));
+        return FRHOT_OK;
+    }
+    // C2f: `buf` holds the (2 + n) halves side by side, `tmp` a bottleneck's inner map
+    int c2f(const char* name, DetSlice in, const char* buf, const char* tmp, DetSlice out, int n, bool shortcut) const {
+        const DetTensor& bt = d->t.at(buf);
+        const int c = bt.c / (2 + n);
+        char l[32];
+        snprintf(l, sizeof l, "%s.cv1", name);
+        int rc = conv(l, in, part(buf, 0, 2 * c), 1, true);
+        for (int j = 0; j < n && !rc; ++j) {
+            const DetSlice src = part(buf, (1 + j) * c, c);
+            snprintf(l, sizeof l, "%s.m%d.cv1", name, j);
+            rc = conv(l, src, all(tmp), 1, true);
+            if (rc) break;
+            snprintf(l, sizeof l, "%s.m%d.cv2", name, j);
+            rc = conv(l, all(tmp), part(buf, (2 + j) * c, c), 1, true, shortcut ? &src : nullptr);
+        }
+        if (rc) return rc;
+        snprintf(l, sizeof l, "%s.cv2", name);
+        return conv(l, all(buf), out, 1, true);
+    }
+    int up2(DetSlice in, DetSlice out) const {
+        HIP_TRY(launch_det_upsample2(in.t->p, in.t->c, in.c0, out.t->p, out.t->c, out.c0, in.c, in.t->h, in.t->w, B, s));
+        return FRHOT_OK;
+    }
+    int pool5(DetSlice in, DetSlice out) const {
+        HIP_TRY(launch_det_maxpool5(in.t->p, in.t->c, in.c0, out.t->p, out.t->c, out.c0, in.c, in.t->h, in.t->w, B, s));
+        return FRHOT_OK;
+    }
+};
+
+// The whole forward pass for B letterboxed frames in tensor "in" (enqueue only).
+int det_forward_enqueue(frhot_detector* d, int B) {
+    DetRun r{d, B, d->ctx->stream};
+#define FR_DET(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
+    FR_DET(r.conv("m0", r.all("in"), r.all("m0"), 2, true));
+    FR_DET(r.conv("m1", r.all("m0"), r.all("m1"), 2, true));
+    FR_DET(r.c2f("m2", r.all("m1"), "c2", "t2", r.all("m2"), 1, true));
+    FR_DET(r.conv("m3", r.all("m2"), r.all("m3"), 2, true));
+    FR_DET(r.c2f("m4", r.all("m3"), "c4", "t4", r.part("cat14", 128, 64), 2, true));          // P3, second part of cat(13, 4)
+    FR_DET(r.conv("m5", r.part("cat14", 128, 64), r.all("m5"), 2, true));
+    FR_DET(r.c2f("m6", r.all("m5"), "c6", "t6", r.part("cat11", 256, 128), 2, true));         // P4, second part of cat(10, 6)
+    FR_DET(r.conv("m7", r.part("cat11", 256, 128), r.all("m7"), 2, true));
+    FR_DET(r.c2f("m8", r.all("m7"), "c8", "t8", r.all("m8"), 1, true));
+    FR_DET(r.conv("m9.cv1", r.all("m8"), r.part("cat9", 0, 128), 1, true));
+    FR_DET(r.pool5(r.part("cat9", 0, 128), r.part("cat9", 128, 128)));
+    FR_DET(r.pool5(r.part("cat9", 128, 128), r.part("cat9", 256, 128)));
+    FR_DET(r.pool5(r.part("cat9", 256, 128), r.part("cat9", 384, 128)));
+    FR_DET(r.conv("m9.cv2", r.all("cat9"), r.part("cat20", 128, 256), 1, true));                // P5, second part of cat(19, 9)
+    FR_DET(r.up2(r.part("cat20", 128, 256), r.part("cat11", 0, 256)));
+    FR_DET(r.c2f("m12", r.all("cat11"), "c12", "t12", r.part("cat17", 64, 128), 1, false));     // second part of cat(16, 12)
+    FR_DET(r.up2(r.part("cat17", 64, 128), r.part("cat14", 0, 128)));
+    FR_DET(r.c2f("m15", r.all("cat14"), "c15", "t15", r.all("o3"), 1, false));
+    FR_DET(r.conv("m16", r.all("o3"), r.part("cat17", 0, 64), 2, true));
+    FR_DET(r.c2f("m18", r.all("cat17"), "c18", "t18", r.all("o4"), 1, false));
+    FR_DET(r.conv("m19", r.all("o4"), r.part("cat20", 0, 128), 2, true));
+    FR_DET(r.c2f("m21", r.all("cat20"), "c21", "t21", r.all("o5"), 1, false));
+    static const char* feat[3] = {"o3", "o4", "o5"};
+    for (int l = 0; l < 3; ++l) {
+        char a[32], b[32], o[32], n0[32], n1[32], n2[32];
+        static const char* br[3] = {"box", "cls", "kpt"};
+        for (int k = 0; k < 3; ++k) {
+            snprintf(a, sizeof a, k == 2 ? "hk%da" : "h%da", l);
+            snprintf(b, sizeof b, k == 2 ? "hk%db" : "h%db", l);
+            snprintf(o, sizeof o, "%s%d", br[k], l);
+            snprintf(n0, sizeof n0, "h.%s%d.0", br[k], l);
+            snprintf(n1, sizeof n1, "h.%s%d.1", br[k], l);
+            snprintf(n2, sizeof n2, "h.%s%d.2", br[k], l);
+            FR_DET(r.conv(n0, r.all(feat[l]), r.all(a), 1, true));
+            FR_DET(r.conv(n1, r.all(a), r.all(b), 1, true));
+            FR_DET(r.conv(n2, r.all(b), r.all(o), 1, false));
+        }
+    }
+#undef FR_DET
+    return FRHOT_OK;
+}
+
+struct DetBox { float v[20]; int anchor; };
+
+float det_iou(const float* a, const float* b) {
+    const float ax1 = a[0] - a[2] / 2, ay1 = a[1] - a[3] / 2, ax2 = a[0] + a[2] / 2, ay2 = a[1] + a[3] / 2;
+    const float bx1 = b[0] - b[2] / 2, by1 = b[1] - b[3] / 2, bx2 = b[0] + b[2] / 2, by2 = b[1] + b[3] / 2;
+    const float iw = std::max(0.f, std::min(ax2, bx2) - std::max(ax1, bx1));
+    const float ih = std::max(0.f, std::min(ay2, by2) - std::max(ay1, by1));
+    const float inter = iw * ih;
+    return inter / (a[2] * a[3] + b[2] * b[3] - inter + 1e-7f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int frhot_det_create(frhot_ctx* c, const void* blob_v, size_t nbytes, int max_batch, frhot_detector** out) {
+    return guarded([&]() -> int {
+    if (!c || !blob_v || !out) return fail(FRHOT_EINVAL, "null argument");
+    if (max_batch <= 0 || max_batch > 64) return fail(FRHOT_ECAPACITY, "max_batch %d outside 1..64", max_batch);
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    std::unique_ptr<frhot_detector> d(new (std::nothrow) frhot_detector());
+    if (!d) return fail(FRHOT_EHIP, "out of host memory");
+    d->ctx = c; d->max_batch = max_batch;
+    struct Cleanup {
+        std::unique_ptr<frhot_detector>& d; bool armed = true;
+        ~Cleanup() { if (armed && d) { for (void* p : d->owned) (void)hipFree(p); if (d->img_pin) (void)hipHostFree(d->img_pin);
+                                       if (d->cand_pin) (void)hipHostFree(d->cand_pin); if (d->count_pin) (void)hipHostFree(d->count_pin); } }
+    } cleanup{d};
+    const uint8_t* blob = (const uint8_t*)blob_v;
+    int rc = FRHOT_OK;
+    auto L = [&](const char* name, int k, int cin, int cout) { if (!rc) rc = det_load_layer(d.get(), blob, nbytes, name, k, cin, cout); };
+    auto C2 = [&](const char* name, int c1, int c2, int n) {
+        char l[32];
+        const int ch = c2 / 2;
+        snprintf(l, sizeof l, "%s.cv1", name); L(l, 1, c1, c2);
+        for (int j = 0; j < n; ++j) {
+            snprintf(l, sizeof l, "%s.m%d.cv1", name, j); L(l, 3, ch, ch);
+            snprintf(l, sizeof l, "%s.m%d.cv2", name, j); L(l, 3, ch, ch);
+        }
+        snprintf(l, sizeof l, "%s.cv2", name); L(l, 1, (2 + n) * ch, c2);
+    };
+    L("m0", 3, 3, 16); L("m1", 3, 16, 32); C2("m2", 32, 32, 1); L("m3", 3, 32, 64); C2("m4", 64, 64, 2);
+    L("m5", 3, 64, 128); C2("m6", 128, 128, 2); L("m7", 3, 128, 256); C2("m8", 256, 256, 1);
+    L("m9.cv1", 1, 256, 128); L("m9.cv2", 1, 512, 256);
+    C2("m12", 384, 128, 1); C2("m15", 192, 64, 1); L("m16", 3, 64, 64); C2("m18", 192, 128, 1);
+    L("m19", 3, 128, 128); C2("m21", 384, 256, 1);
+    static const int fch[3] = {64, 128, 256};
+    for (int l = 0; l < 3; ++l) {
+        char n[32];
+        snprintf(n, sizeof n, "h.box%d.0", l); L(n, 3, fch[l], 64);
+        snprintf(n, sizeof n, "h.box%d.1", l); L(n, 3, 64, 64);
+        snprintf(n, sizeof n, "h.box%d.2", l); L(n, 1, 64, 64);
+        snprintf(n, sizeof n, "h.cls%d.0", l); L(n, 3, fch[l], 64);
+        snprintf(n, sizeof n, "h.cls%d.1", l); L(n, 3, 64, 64);
+        snprintf(n, sizeof n, "h.cls%d.2", l); L(n, 1, 64, 1);
+        snprintf(n, sizeof n, "h.kpt%d.0", l); L(n, 3, fch[l], 16);
+        snprintf(n, sizeof n, "h.kpt%d.1", l); L(n, 3, 16, 16);
+        snprintf(n, sizeof n, "h.kpt%d.2", l); L(n, 1, 16, 15);
+    }
+    if (rc) return rc;
+    auto T = [&](const char* name, int hw, int ch) { if (!rc) rc = det_tensor(d.get(), name, hw, hw, ch); };
+    T("in", 640, 16); T("m0", 320, 16); T("m1", 160, 32); T("c2", 160, 48); T("t2", 160, 16); T("m2", 160, 32);
+    T("m3", 80, 64); T("c4", 80, 128); T("t4", 80, 32); T("cat14", 80, 192);
+    T("m5", 40, 128); T("c6", 40, 256); T("t6", 40, 64); T("cat11", 40, 384);
+    T("m7", 20, 256); T("c8", 20, 384); T("t8", 20, 128); T("m8", 20, 256); T("cat9", 20, 512); T("cat20", 20, 384);
+    T("c12", 40, 192); T("t12", 40, 64); T("cat17", 40, 192);
+    T("c15", 80, 96); T("t15", 80, 32); T("o3", 80, 64);
+    T("c18", 40, 192); T("t18", 40, 64); T("o4", 40, 128);
+    T("c21", 20, 384); T("t21", 20, 128); T("o5", 20, 256);
+    static const int fhw[3] = {80, 40, 20};
+    for (int l = 0; l < 3; ++l) {
+        char n[32];
+        snprintf(n, sizeof n, "h%da", l); T(n, fhw[l], 64);
+        snprintf(n, sizeof n, "h%db", l); T(n, fhw[l], 64);
+        snprintf(n, sizeof n, "hk%da", l); T(n, fhw[l], 16);
+        snprintf(n, sizeof n, "hk%db", l); T(n, fhw[l], 16);
+        snprintf(n, sizeof n, "box%d", l); T(n, fhw[l], 64);
+        snprintf(n, sizeof n, "cls%d", l); T(n, fhw[l], 16);
+        snprintf(n, sizeof n, "kpt%d", l); T(n, fhw[l], 16);
+    }
+    if (rc) return rc;
+    rc = det_alloc(d.get(), (void**)&d->meta_dev, sizeof(DetImageMeta) * max_batch);
+    if (!rc) rc = det_alloc(d.get(), (void**)&d->cand_dev, sizeof(DetCand) * (size_t)max_batch * frhot_detector::kCap);
+    if (!rc) rc = det_alloc(d.get(), (void**)&d->count_dev, sizeof(int) * max_batch);
+    if (rc) return rc;
+    HIP_TRY(hipHostMalloc((void**)&d->cand_pin, sizeof(DetCand) * (size_t)max_batch * frhot_detector::kCap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&d->count_pin, sizeof(int) * max_batch, hipHostMallocDefault));
+    cleanup.armed = false;
+    *out = d.release();
+    return FRHOT_OK;
+    });
+}
+
+int frhot_det_destroy(frhot_detector* d) {
+    return guarded([&]() -> int {
+    if (!d) return FRHOT_OK;
+    {
+        std::lock_guard<std::mutex> lk(d->ctx->mu);
+        DeviceGuard dg(d->ctx->device);
+        (void)hipStreamSynchronize(d->ctx->stream);
+        for (void* p : d->owned) (void)hipFree(p);
+        if (d->img_dev) (void)hipFree(d->img_dev);
+        if (d->img_pin) (void)hipHostFree(d->img_pin);
+        if (d->cand_pin) (void)hipHostFree(d->cand_pin);
+        if (d->count_pin) (void)hipHostFree(d->count_pin);
+    }
+    delete d;
+    return FRHOT_OK;
+    });
+}
+
+int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int32_t* hw, const int32_t* strides, int B,
+                     float conf, float iou, int max_faces, float* out, int32_t* counts) {
+    return guarded([&]() -> int {
+    if (!d || !images || !hw || !strides || !out || !counts) return fail(FRHOT_EINVAL, "null argument");
+    if (B <= 0 || B > d->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, d->max_batch);
+    if (max_faces <= 0 || max_faces > 300) return fail(FRHOT_EINVAL, "max_faces %d outside 1..300", max_faces);
+    if (!(conf > 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return fail(FRHOT_EINVAL, "conf %g / iou %g out of range", conf, iou);
+    frhot_ctx* c = d->ctx;
+    std::vector<DetImageMeta> meta(B);
+    size_t total = 0;
+    for (int i = 0; i < B; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h <= 0 || w <= 0 || h > 16384 || w > 16384 || strides[i] < 3 * w || !images[i])
+            return fail(FRHOT_EINVAL, "bad image %d: %dx%d stride %d", i, h, w, strides[i]);
+        DetImageMeta& m = meta[i];
+        m.offset = (int64_t)total; m.h = h; m.w = w; m.stride = 3 * w;
+        // ratio and new size as ultralytics' LetterBox computes them (float64, Python round = half to even)
+        const double r = std::min(640.0 / h, 640.0 / w);
+        m.nw = (int)std::nearbyint(w * r); m.nh = (int)std::nearbyint(h * r);
+        if (m.nw < 1 || m.nh < 1) return fail(FRHOT_EINVAL, "image %d: %dx%d letterboxes to an empty image", i, h, w);
+        const double dw = (640 - m.nw) / 2.0, dh = (640 - m.nh) / 2.0;
+        m.top = (int)std::nearbyint(dh - 0.1); m.left = (int)std::nearbyint(dw - 0.1);
+        m.sy = (double)h / m.nh; m.sx = (double)w / m.nw;
+        total += ((size_t)h * 3 * w + 15) & ~(size_t)15;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    hipStream_t s = c->stream;
+    if (total > d->img_cap) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (d->img_dev) { HIP_TRY(hipFree(d->img_dev)); d->img_dev = nullptr; d->img_cap = 0; }
+        if (d->img_pin) { HIP_TRY(hipHostFree(d->img_pin)); d->img_pin = nullptr; }
+        const size_t cap = total + total / 4 + 4096;
+        HIP_TRY(hipMalloc((void**)&d->img_dev, cap));
+        HIP_TRY(hipHostMalloc((void**)&d->img_pin, cap, hipHostMallocDefault));
+        d->img_cap = cap;
+    }
+    for (int i = 0; i < B; ++i) {
+        const size_t h = (size_t)hw[2 * i], row = (size_t)3 * hw[2 * i + 1];
+        uint8_t* dst = d->img_pin + meta[i].offset;
+        if ((size_t)strides[i] == row) memcpy(dst, images[i], h * row);
+        else for (size_t y = 0; y < h; ++y) memcpy(dst + y * row, images[i] + y * (size_t)strides[i], row);
+    }
+    HIP_TRY(hipMemcpyAsync(d->img_dev, d->img_pin, total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d->meta_dev, meta.data(), sizeof(DetImageMeta) * B, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_det_letterbox(d->img_dev, d->meta_dev, d->t.at("in").p, B, s));
+    int rc = det_forward_enqueue(d, B);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    DetHead heads[3];
+    static const int strides_l[3] = {8, 16, 32};
+    for (int l = 0; l < 3; ++l) {
+        char n[16];
+        snprintf(n, sizeof n, "box%d", l); heads[l].box = d->t.at(n).p; heads[l].h = d->t.at(n).h; heads[l].w = d->t.at(n).w;
+        snprintf(n, sizeof n, "cls%d", l); heads[l].cls = d->t.at(n).p;
+        snprintf(n, sizeof n, "kpt%d", l); heads[l].kpt = d->t.at(n).p;
+        heads[l].stride = strides_l[l];
+    }
+    HIP_TRY(launch_det_decode(heads, conf, d->cand_dev, d->count_dev, frhot_detector::kCap, B, s));
+    HIP_TRY(hipMemcpyAsync(d->count_pin, d->count_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // the survivors of every image, then suppression and the way back to the frame, on the host (a handful of boxes)
+    for (int i = 0; i < B; ++i) {
+        int n = d->count_pin[i];
+        if (n > frhot_detector::kCap)
+            return fail(FRHOT_ECAPACITY, "image %d: %d anchors above the confidence threshold (at most %d are kept)", i, n, frhot_detector::kCap);
+        if (n > 0)
+            HIP_TRY(hipMemcpy(d->cand_pin + (size_t)i * frhot_detector::kCap, d->cand_dev + (size_t)i * frhot_detector::kCap,
+                              sizeof(DetCand) * n, hipMemcpyDeviceToHost));
+        const DetCand* cand = d->cand_pin + (size_t)i * frhot_detector::kCap;
+        std::vector<int> order(n);
+        for (int j = 0; j < n; ++j) order[j] = j;
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            if (cand[a].v[4] != cand[b].v[4]) return cand[a].v[4] > cand[b].v[4];
+            return cand[a].anchor < cand[b].anchor;
+        });
+        std::vector<int> kept;
+        for (int j : order) {
+            bool ok = true;
+            for (int q : kept) if (det_iou(cand[j].v, cand[q].v) > iou) { ok = false; break; }
+            if (ok) { kept.push_back(j); if ((int)kept.size() == max_faces) break; }
+        }
+        const DetImageMeta& m = meta[i];
+        const double r = std::min(640.0 / m.h, 640.0 / m.w);
+        auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        float* o = out + (size_t)i * max_faces * 20;
+        for (size_t q = 0; q < kept.size(); ++q) {
+            const float* v = cand[kept[q]].v;
+            float* w = o + q * 20;
+            w[0] = (float)clampd((v[0] - v[2] / 2 - m.left) / r, 0, m.w);
+            w[1] = (float)clampd((v[1] - v[3] / 2 - m.top) / r, 0, m.h);
+            w[2] = (float)clampd((v[0] + v[2] / 2 - m.left) / r, 0, m.w);
+            w[3] = (float)clampd((v[1] + v[3] / 2 - m.top) / r, 0, m.h);
+            w[4] = v[4];
+            for (int k = 0; k < 5; ++k) {
+                w[5 + 3 * k] = (float)clampd((v[5 + 3 * k] - m.left) / r, 0, m.w);
+                w[6 + 3 * k] = (float)clampd((v[6 + 3 * k] - m.top) / r, 0, m.h);
+                w[7 + 3 * k] = v[7 + 3 * k];
+            }
+        }
+        counts[i] = (int32_t)kept.size();
+    }
+    return FRHOT_OK;
+    });
+}
+
+int frhot_det_debug_read(frhot_detector* d, const char* name, int B, void* host_out, size_t nbytes) {
+    return guarded([&]() -> int {
+    if (!d || !name || !host_out) return fail(FRHOT_EINVAL, "null argument");
+    if (B <= 0 || B > d->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, d->max_batch);
+    const auto it = d->t.find(name);
+    if (it == d->t.end()) return fail(FRHOT_EINVAL, "the detector has no tensor '%s'", name);
+    const size_t need = (size_t)B * it->second.h * it->second.w * it->second.c * 2;
+    if (nbytes != need) return fail(FRHOT_EINVAL, "tensor '%s' of %d images is %zu bytes, the buffer %zu", name, B, need, nbytes);
+    std::lock_guard<std::mutex> lk(d->ctx->mu);
+    DeviceGuard dg(d->ctx->device);
+    HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+    HIP_TRY(hipMemcpy(host_out, it->second.p, need, hipMemcpyDeviceToHost));
     return FRHOT_OK;
     });
 }

@@ -47,6 +47,28 @@ hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, 
 hipError_t launch_wino_weights(const void* w, void* U, int cin, int cout, hipStream_t s);
 hipError_t launch_conv3x3_wino(const ConvLayerDesc& d, const void* x, const void* U, const float* bias, void* y,
                                int B, hipStream_t s);
+// ---- face detector (YOLOv8n-pose layout): NHWC fp16 tensors addressed as channel slices ----
+struct DetConv {
+    const _Float16* x; int H, W, xc, xc0, cin;       // input [B,H,W,xc], channels xc0 .. xc0+cin (cin % 16 == 0)
+    const _Float16* w; const float* b;               // [cout][k][k][cin] fp16, [cout] fp32 (cout % 16 == 0)
+    _Float16* y; int Ho, Wo, yc, yc0, cout;          // output [B,Ho,Wo,yc], channels yc0 .. yc0+cout
+    const _Float16* r; int rc, rc0;                  // residual slice (output geometry) added after the activation, or null
+    int k, stride, act;                              // k in {1,3}, stride in {1,2} (k=1: stride 1), act: SiLU
+};
+struct DetImageMeta {
+    int64_t offset; int h, w, stride;                // the frame inside the staged bytes
+    int nh, nw, top, left;                           // resized size and its place on the 640 x 640 canvas
+    double sy, sx;                                   // source pixels per resized pixel
+};
+struct DetHead { const _Float16 *box, *cls, *kpt; int h, w, stride; };   // [B,h,w,64], [B,h,w,16] (channel 0), [B,h,w,16] (15)
+struct DetCand { float v[20]; int anchor; };         // cx, cy, w, h (canvas), score, 5 x (x, y, visibility)
+hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s);
+hipError_t launch_det_maxpool5(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
+                               hipStream_t s);
+hipError_t launch_det_upsample2(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
+                                hipStream_t s);
+hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out16, int B, hipStream_t s);
+hipError_t launch_det_decode(const DetHead* heads3, float conf, DetCand* cand, int* counts, int cap, int B, hipStream_t s);
 // Split-K GEMM partial[z][m][n] = sum_{k in slice z} x[m][k] * w[n][k]; M rows of x,
 // N rows of w, K multiple of 64*splitk, N multiple of 128.
 hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M, int N, int K,

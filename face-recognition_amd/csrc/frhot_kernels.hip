@@ -3374,6 +3374,233 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const half_t* __restr
 
 #endif  // FR_WINOGRAD
 
+// ------------------------------------------------------------ face detector ---
+// The detector behind the reference's DeepFace.extract_faces(detector_backend="yolov8")
+// (app/src/utils/legacy.py:60-65,80-86): a YOLOv8n-pose network (one class, five keypoints) on a
+// 640 x 640 letterboxed frame.  Sixty-odd small convolutions (16..256 channels), so one generic
+// kernel serves them all: NHWC fp16 tensors addressed as channel slices (a concatenation is two
+// producers writing into one tensor), folded batch norm as a bias, SiLU and the bottleneck's
+// residual in the epilogue.  A wave computes 32 pixels x up to 64 channels with
+// v_mfma_f32_16x16x16_f16, both operands straight from global memory (the weights of a layer
+// are a few KiB to 1 MiB and stay in L2; no LDS).
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+template <int KS, int ST>
+__global__ __launch_bounds__(256) void det_conv_kernel(DetConv d, int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * 64;
+    const int nsub = (d.cout - n0) / 16 < 4 ? (d.cout - n0) / 16 : 4;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    if (m0 >= M) return;
+    const int HWo = d.Ho * d.Wo;
+    int pb[2], py[2], px[2];
+    bool pv[2];
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg) {
+        const int m = m0 + pg * 16 + l15;
+        pv[pg] = m < M;
+        const int mm = pv[pg] ? m : M - 1;
+        pb[pg] = mm / HWo;
+        const int rem = mm - pb[pg] * HWo;
+        py[pg] = rem / d.Wo;
+        px[pg] = rem - py[pg] * d.Wo;
+    }
+    float4v acc[4][2];
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) acc[ns][pg] = float4v{0.f, 0.f, 0.f, 0.f};
+    const long wrow = (long)KS * KS * d.cin;            // halfs per output channel
+    const half4v zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const half_t* xp[2];
+            bool ok[2];
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                const int iy = py[pg] * ST + ky - KS / 2, ix = px[pg] * ST + kx - KS / 2;
+                ok[pg] = pv[pg] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+                const int cy = ok[pg] ? iy : 0, cx = ok[pg] ? ix : 0;
+                xp[pg] = d.x + (((long)pb[pg] * d.H + cy) * d.W + cx) * d.xc + d.xc0 + 4 * g;
+            }
+            const half_t* wp = d.w + ((long)(n0 + l15) * KS * KS + ky * KS + kx) * d.cin + 4 * g;
+            for (int cg = 0; cg < d.cin; cg += 16) {
+                half4v bf[2];
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg) bf[pg] = ok[pg] ? *(const half4v*)(xp[pg] + cg) : zero4;
+#pragma unroll
+                for (int ns = 0; ns < 4; ++ns) {
+                    if (ns < nsub) {
+                        const half4v af = *(const half4v*)(wp + ns * 16 * wrow + cg);
+#pragma unroll
+                        for (int pg = 0; pg < 2; ++pg)
+                            acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x16f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns) {
+        if (ns >= nsub) continue;
+        const int n = n0 + ns * 16 + 4 * g;
+        const float4v bv = *(const float4v*)(d.b + n);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+            if (!pv[pg]) continue;
+            const long pix = ((long)pb[pg] * d.Ho + py[pg]) * d.Wo + px[pg];
+            half4v o;
+            half4v rr = zero4;
+            if (d.r) rr = *(const half4v*)(d.r + pix * d.rc + d.rc0 + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[ns][pg][j] + bv[j];
+                if (d.act) v = v / (1.0f + __expf(-v));
+                if (d.r) v += (float)rr[j];          // the bottleneck adds its input to the ACTIVATED map
+                o[j] = (half_t)v;
+            }
+            *(half4v*)(d.y + pix * d.yc + d.yc0 + n) = o;
+        }
+    }
+}
+
+// 5 x 5 / 1 max pool with "same" padding over C channels of a slice, 8 channels per thread
+__global__ __launch_bounds__(256) void det_maxpool5_kernel(const half_t* __restrict__ x, int xc, int xc0,
+                                                           half_t* __restrict__ y, int yc, int yc0, int C, int H, int W,
+                                                           long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C / 8;
+    const int ch = (int)(i % c8) * 8;
+    const long p = i / c8;
+    const int px = (int)(p % W), py = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    half8 m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = (half_t)-65504.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = px + dx;
+            if (xx < 0 || xx >= W) continue;
+            const half8 v = *(const half8*)(x + ((b * H + yy) * W + xx) * xc + xc0 + ch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+    }
+    *(half8*)(y + ((b * H + py) * W + px) * yc + yc0 + ch) = m;
+}
+
+// nearest-neighbour x2 of a [B,H,W,C] slice into a [B,2H,2W,.] slice
+__global__ __launch_bounds__(256) void det_upsample2_kernel(const half_t* __restrict__ x, int xc, int xc0,
+                                                            half_t* __restrict__ y, int yc, int yc0, int C, int H, int W,
+                                                            long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C / 8;
+    const int ch = (int)(i % c8) * 8;
+    const long p = i / c8;
+    const int W2 = 2 * W, H2 = 2 * H;
+    const int px = (int)(p % W2), py = (int)((p / W2) % H2);
+    const long b = p / ((long)W2 * H2);
+    *(half8*)(y + ((b * H2 + py) * W2 + px) * yc + yc0 + ch) =
+        *(const half8*)(x + ((b * H + (py >> 1)) * W + (px >> 1)) * xc + xc0 + ch);
+}
+
+// Letterbox of a BGR frame onto the 640 x 640 canvas: bilinear resize with half-pixel centres
+// (float32, rounded to whole levels as a uint8 resize returns them), 114 outside, RGB order,
+// / 255, written as 16 channels (13 zeros) so that the first convolution is an ordinary one.
+__global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __restrict__ imgs,
+                                                            const DetImageMeta* __restrict__ meta,
+                                                            half_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;       // canvas pixel
+    if (p >= 640 * 640) return;
+    const DetImageMeta m = meta[b];
+    const int cy = p / 640, cx = p - cy * 640;
+    float rgb[3] = {114.f, 114.f, 114.f};
+    const int y = cy - m.top, x = cx - m.left;
+    if (y >= 0 && y < m.nh && x >= 0 && x < m.nw) {
+        const uint8_t* src = imgs + m.offset;
+        float bgr[3];
+        if (m.nh == m.h && m.nw == m.w) {
+            const uint8_t* q = src + (long)y * m.stride + 3 * x;
+            bgr[0] = q[0]; bgr[1] = q[1]; bgr[2] = q[2];
+        } else {
+            const double fy = ((double)y + 0.5) * m.sy - 0.5, fx = ((double)x + 0.5) * m.sx - 0.5;
+            const double y0d = floor(fy), x0d = floor(fx);
+            const float ay = (float)(fy - y0d), ax = (float)(fx - x0d);
+            const int y0 = (int)y0d, x0 = (int)x0d;
+            const int y0c = min(max(y0, 0), m.h - 1), y1c = min(max(y0 + 1, 0), m.h - 1);
+            const int x0c = min(max(x0, 0), m.w - 1), x1c = min(max(x0 + 1, 0), m.w - 1);
+            const uint8_t* r0 = src + (long)y0c * m.stride;
+            const uint8_t* r1 = src + (long)y1c * m.stride;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t0 = (float)r0[3 * x0c + c] * (1.0f - ax) + (float)r0[3 * x1c + c] * ax;
+                const float t1 = (float)r1[3 * x0c + c] * (1.0f - ax) + (float)r1[3 * x1c + c] * ax;
+                bgr[c] = floorf(t0 * (1.0f - ay) + t1 * ay + 0.5f);
+            }
+        }
+        rgb[0] = bgr[2]; rgb[1] = bgr[1]; rgb[2] = bgr[0];
+    }
+    half8 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lo[e] = (half_t)0.f; hi[e] = (half_t)0.f; }
+    lo[0] = (half_t)(rgb[0] / 255.0f); lo[1] = (half_t)(rgb[1] / 255.0f); lo[2] = (half_t)(rgb[2] / 255.0f);
+    half_t* o = out + ((long)b * 640 * 640 + p) * 16;
+    *(half8*)o = lo;
+    *(half8*)(o + 8) = hi;
+}
+
+// Head maps of the three levels -> the anchors whose class score exceeds `conf`: xywh on the canvas,
+// score, five keypoints (x, y, visibility), anchor number.  One thread per anchor; the survivors
+// of an image are appended through one counter per image (their order is made definite on the host).
+__global__ __launch_bounds__(256) void det_decode_kernel(DetHead h0, DetHead h1, DetHead h2, float conf,
+                                                         DetCand* __restrict__ cand, int* __restrict__ counts, int cap) {
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = h0.h * h0.w, n1 = h1.h * h1.w, n2 = h2.h * h2.w;
+    if (a >= n0 + n1 + n2) return;
+    const DetHead h = a < n0 ? h0 : (a < n0 + n1 ? h1 : h2);
+    const int i = a < n0 ? a : (a < n0 + n1 ? a - n0 : a - n0 - n1);
+    const int cy = i / h.w, cx = i - cy * h.w;
+    const long pix = ((long)b * h.h + cy) * h.w + cx;
+    const float logit = (float)h.cls[pix * 16];
+    const float score = 1.0f / (1.0f + __expf(-logit));
+    if (!(score > conf)) return;
+    float dist[4];
+    const half_t* bp = h.box + pix * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16], mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = (float)bp[s * 16 + k]; mx = fmaxf(mx, v[k]); }
+        float sum = 0.f, ex = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float e = __expf(v[k] - mx); sum += e; ex += e * (float)k; }
+        dist[s] = ex / sum;
+    }
+    const float ax = (float)cx + 0.5f, ay = (float)cy + 0.5f, st = (float)h.stride;
+    const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    const int slot = atomicAdd(counts + b, 1);
+    if (slot >= cap) return;
+    DetCand c;
+    c.v[0] = (x1 + x2) * 0.5f * st; c.v[1] = (y1 + y2) * 0.5f * st; c.v[2] = (x2 - x1) * st; c.v[3] = (y2 - y1) * st;
+    c.v[4] = score;
+    const half_t* kp = h.kpt + pix * 16;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        c.v[5 + 3 * k] = ((float)kp[3 * k] * 2.0f + (ax - 0.5f)) * st;
+        c.v[6 + 3 * k] = ((float)kp[3 * k + 1] * 2.0f + (ay - 0.5f)) * st;
+        c.v[7 + 3 * k] = 1.0f / (1.0f + __expf(-(float)kp[3 * k + 2]));
+    }
+    c.anchor = a;
+    cand[(long)b * cap + slot] = c;
+}
+
 // ---------------------------------------------------------------- launch ---
 #define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -3649,6 +3876,60 @@ hipError_t launch_gallery_scatter(const void* in, const int32_t* in_keys, const 
 hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStream_t s) {
     if (Bq <= 0 || !q || !o || D % 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(f32_to_unit_f16_kernel, dim3((Bq + 3) / 4), dim3(256), 0, s, q, (half_t*)o, Bq, D);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+// ---- face detector ----
+hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
+    if (B <= 0 || !d.x || !d.w || !d.b || !d.y || d.cin % 16 || d.cout % 16 || d.cin <= 0 || d.cout <= 0)
+        return hipErrorInvalidValue;
+    if ((d.xc0 | d.yc0 | d.xc | d.yc) % 4 || (d.r && (d.rc0 | d.rc) % 4)) return hipErrorInvalidValue;   // 8-byte accesses
+    const long M = (long)B * d.Ho * d.Wo;
+    if (M <= 0 || M > 0x7fffffffL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((d.cout + 63) / 64));
+    if (d.k == 3 && d.stride == 1) hipLaunchKernelGGL((det_conv_kernel<3, 1>), grid, dim3(256), 0, s, d, (int)M);
+    else if (d.k == 3 && d.stride == 2) hipLaunchKernelGGL((det_conv_kernel<3, 2>), grid, dim3(256), 0, s, d, (int)M);
+    else if (d.k == 1 && d.stride == 1) hipLaunchKernelGGL((det_conv_kernel<1, 1>), grid, dim3(256), 0, s, d, (int)M);
+    else return hipErrorInvalidValue;
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_det_maxpool5(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
+                               hipStream_t s) {
+    if (B <= 0 || !x || !y || C % 8 || (xc | xc0 | yc | yc0) % 8) return hipErrorInvalidValue;
+    const long total = (long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(det_maxpool5_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t*)x, xc,
+                       xc0, (half_t*)y, yc, yc0, C, H, W, total);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_det_upsample2(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
+                                hipStream_t s) {
+    if (B <= 0 || !x || !y || C % 8 || (xc | xc0 | yc | yc0) % 8) return hipErrorInvalidValue;
+    const long total = (long)B * 4 * H * W * (C / 8);
+    hipLaunchKernelGGL(det_upsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const half_t*)x, xc,
+                       xc0, (half_t*)y, yc, yc0, C, H, W, total);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out16, int B, hipStream_t s) {
+    if (B <= 0 || !imgs || !meta || !out16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(det_letterbox_kernel, dim3(1600, B), dim3(256), 0, s, imgs, meta, (half_t*)out16);
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+hipError_t launch_det_decode(const DetHead* heads3, float conf, DetCand* cand, int* counts, int cap, int B, hipStream_t s) {
+    if (B <= 0 || !heads3 || !cand || !counts || cap <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)B, s);
+    if (e != hipSuccess) return e;
+    const int n = heads3[0].h * heads3[0].w + heads3[1].h * heads3[1].w + heads3[2].h * heads3[2].w;
+    hipLaunchKernelGGL(det_decode_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, heads3[0], heads3[1], heads3[2], conf,
+                       cand, counts, cap);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

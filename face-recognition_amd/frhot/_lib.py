@@ -53,6 +53,10 @@ SIGNATURES = {
     "frhot_dist_init": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "frhot_dist_shutdown": (C.c_int, [_p]),
     "frhot_search_sharded_dev": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, _p, _p, C.c_int64]),
+    "frhot_det_create": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "frhot_det_destroy": (C.c_int, [_p]),
+    "frhot_det_detect": (C.c_int, [_p, _u8pp, _i32p, _i32p, C.c_int, C.c_float, C.c_float, C.c_int, _f32p, _i32p]),
+    "frhot_det_debug_read": (C.c_int, [_p, C.c_char_p, C.c_int, _p, C.c_size_t]),
     "frhot_recognise": (C.c_int, [_p, _p, _u8pp, _i32p, _i32p, _i32p, C.c_int, C.c_uint, C.c_int,
                                   _f32p, _f32p, _i64p]),
     "frhot_crop_sharpness": (C.c_int, [_p, _u8pp, _i32p, _i32p, C.c_int, _i64p]),

@@ -129,6 +129,11 @@ def pack_blob(weights: dict) -> np.ndarray:
             raise ValueError(f"{name}.b has shape {b.shape}")
         entries.append((name + ".w", 0, w))
         entries.append((name + ".b", 1, b))
+    return pack_entries(entries)
+
+
+def pack_entries(entries) -> np.ndarray:
+    """[(name (at most 15 characters), dtype code (0 fp16, 1 fp32), array)] -> uint8 blob."""
     head = 16 + _ENTRY.size * len(entries)
     off = (head + 63) & ~63
     layout = []

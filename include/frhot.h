@@ -285,6 +285,33 @@ int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, cons
                              int B, int k, void* scores_dev, void* rows_dev, int64_t row_base);
 
 /*
+ * The face detector of the reference's DeepFace.extract_faces(detector_backend="yolov8") calls
+ * (app/src/utils/legacy.py:60-65 on the whole frame, :80-86 in detect_face): a YOLOv8n-pose network
+ * with one class and five keypoints (the yolov8n-face.pt file of app/Dockerfile:82-84) on a
+ * 640 x 640 letterboxed frame, then confidence selection and greedy IoU suppression.
+ * frhot_det_create: blob = the library's weight container ("FRHOTW01") holding, for every
+ *   convolution of the network, "<name>.w" fp16 [cout][k][k][cin] with the batch norm folded in and
+ *   "<name>.b" fp32 (names: frhot/detector.py, CONVS).  max_batch <= 64 frames per call; the
+ *   activations take about 42 MB of device memory per frame.
+ * frhot_det_detect: B BGR uint8 frames given like frhot_embed's crops.  For frame i, counts[i]
+ *   faces (at most max_faces <= 300, descending confidence) are written to out[i][j][0..19] =
+ *   x1, y1, x2, y2 in frame pixels (clipped to the frame), confidence, then five keypoints as
+ *   (x, y, visibility): right eye, left eye, nose, right and left mouth corner in image order.
+ *   conf: class score a face must exceed (the reference's backend uses 0.25); iou: boxes that
+ *   overlap a better one by more than this are dropped (0.7).  Waits for the result.
+ *   FRHOT_ECAPACITY when more than 2048 anchors of one frame pass `conf` (not a face detector's
+ *   weights, or a threshold near zero).
+ * frhot_det_debug_read: one named activation tensor of the last call ([B,h,w,c] fp16), for tests.
+ * Anti-spoofing (the `is_real` field DeepFace adds with a second network) is not part of this.
+ */
+typedef struct frhot_detector frhot_detector;
+int frhot_det_create(frhot_ctx* ctx, const void* blob, size_t nbytes, int max_batch, frhot_detector** out);
+int frhot_det_destroy(frhot_detector* det);
+int frhot_det_detect(frhot_detector* det, const uint8_t* const* images, const int32_t* hw, const int32_t* strides,
+                     int B, float conf, float iou, int max_faces, float* out, int32_t* counts);
+int frhot_det_debug_read(frhot_detector* det, const char* name, int B, void* host_out, size_t nbytes);
+
+/*
  * Fused embed -> search on one GPU: B host crops, qkeys[B] (or NULL), top-k
  * against gallery g of dimension D (4096, or < 4096 to match on the leading D
  * components re-normalised).  emb_out may be NULL.

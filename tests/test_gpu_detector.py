@@ -1,0 +1,142 @@
+"""The face detector on the GPU (C ABI: frhot_det_*) against oracle/yolo_face.py: letterbox bit for
+bit, every block's activations, the decoded candidates, and the regions after suppression.
+PARITY UNPINNED: the oracle restates ultralytics / deepface from their published behaviour."""
+import numpy as np
+import pytest
+
+from det_util import calibrated_weights, frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det(gpu_ctx):
+    from frhot import detector as D
+    w, wq = calibrated_weights(seed=3, cls_bias=-6.0)
+    d = D.Detector(gpu_ctx, D.pack_blob(w), max_batch=4)
+    yield d, wq
+    d.close()
+
+
+def test_letterbox_bit_exact(det):
+    from oracle import yolo_face as O
+    d, _wq = det
+    rng = np.random.default_rng(1)
+    shapes = [(480, 640), (640, 640), (1280, 320), (100, 50), (333, 517), (719, 1279), (641, 640), (64, 640)]
+    imgs = [(rng.random((h, w, 3)) * 255).astype(np.uint8) for h, w in shapes]
+    big = (rng.random((500, 700, 3)) * 255).astype(np.uint8)
+    imgs.append(big[20:420, 100:650])                     # a row-strided view
+    for i in range(0, len(imgs), 4):
+        part = imgs[i:i + 4]
+        d.detect(part)
+        got = d.debug_read("in", len(part), 640, 640, 16)
+        for j, im in enumerate(part):
+            want = O.letterbox(im)[0].astype(np.float16)
+            assert np.array_equal(got[j, :, :, :3], want), f"image {i + j} {im.shape}"
+            assert not got[j, :, :, 3:].any()
+
+
+def test_blocks_match_oracle(det):
+    from oracle import yolo_face as O
+    d, wq = det
+    imgs = frames(seed=9, n=2)
+    d.detect(imgs)
+    x = np.stack([O.letterbox(im)[0] for im in imgs])
+    taps = {}
+    outs = O.forward(x, wq, taps)
+    where = {"m0": ("m0", 320, 16, 0), "m1": ("m1", 160, 32, 0), "m2": ("m2", 160, 32, 0), "m3": ("m3", 80, 64, 0),
+             "m4": ("cat14", 80, 192, 128), "m5": ("m5", 40, 128, 0), "m6": ("cat11", 40, 384, 256), "m7": ("m7", 20, 256, 0),
+             "m8": ("m8", 20, 256, 0), "m9": ("cat20", 20, 384, 128), "m12": ("cat17", 40, 192, 64), "m15": ("o3", 80, 64, 0),
+             "m18": ("o4", 40, 128, 0), "m21": ("o5", 20, 256, 0)}
+    for name, (tensor, hw, c, c0) in where.items():
+        ref = taps[name]
+        got = d.debug_read(tensor, 2, hw, hw, c)[..., c0:c0 + ref.shape[-1]].astype(np.float32)
+        err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+        assert err <= 1e-2 * scale, f"{name}: max err {err} vs scale {scale}"
+    for l, (box, cls, kpt) in enumerate(outs):
+        hw = box.shape[1]
+        for nm, ref, c in (("box", box, 64), ("cls", cls, 16), ("kpt", kpt, 16)):
+            got = d.debug_read(f"{nm}{l}", 2, hw, hw, c)[..., :ref.shape[-1]].astype(np.float32)
+            err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+            assert err <= 1.5e-2 * scale, f"{nm}{l}: max err {err} vs scale {scale}"
+
+
+def _match(got, ref_boxes, ref_scores, ref_kpts, tol_px, tol_s):
+    """every reference candidate well clear of the threshold has a device row with the same numbers"""
+    used = set()
+    for b, s, k in zip(ref_boxes, ref_scores, ref_kpts):
+        if abs(s - 0.25) < 0.03:
+            continue
+        best = None
+        for j, row in enumerate(got):
+            if j in used:
+                continue
+            if abs(row[4] - s) <= tol_s and np.abs(row[:4] - b).max() <= tol_px:
+                best = j
+                break
+        assert best is not None, f"no device row for box {b} score {s}"
+        used.add(best)
+        assert np.abs(got[best][5:].reshape(5, 3)[:, :2] - k[:, :2]).max() <= tol_px
+        assert np.abs(got[best][5:].reshape(5, 3)[:, 2] - k[:, 2]).max() <= tol_s
+    return len(used)
+
+
+def test_candidates_match_oracle(det):
+    """iou = 1 suppresses nothing: the device's rows are its decoded candidates (mapped back to the
+    frame), compared with the oracle's decode of its own float32 head maps."""
+    from oracle import yolo_face as O
+    d, wq = det
+    imgs = frames(seed=11, n=3)
+    got = d.detect(imgs, conf=0.25, iou=1.0, max_faces=300)
+    n_checked = 0
+    for im, rows in zip(imgs, got):
+        x, r, (left, top) = O.letterbox(im)
+        boxes, scores, kpts = O.decode(O.forward(x[None], wq))[0]
+        H, W = im.shape[:2]
+        xyxy = np.stack([boxes[:, 0] - boxes[:, 2] / 2, boxes[:, 1] - boxes[:, 3] / 2, boxes[:, 0] + boxes[:, 2] / 2,
+                         boxes[:, 1] + boxes[:, 3] / 2], 1)
+        xyxy[:, [0, 2]] = np.clip((xyxy[:, [0, 2]] - left) / r, 0, W)
+        xyxy[:, [1, 3]] = np.clip((xyxy[:, [1, 3]] - top) / r, 0, H)
+        kp = kpts.copy()
+        kp[:, :, 0] = np.clip((kp[:, :, 0] - left) / r, 0, W)
+        kp[:, :, 1] = np.clip((kp[:, :, 1] - top) / r, 0, H)
+        assert abs(len(rows) - min(len(scores), 300)) <= max(2, len(scores) // 20)
+        assert (np.diff(rows[:, 4]) <= 0).all()
+        if len(scores) <= 300:
+            n_checked += _match(rows, xyxy, scores, kp, tol_px=1.5 / min(r, 1.0), tol_s=0.02)
+    assert n_checked >= 5
+
+
+def test_regions_match_oracle(det):
+    from oracle import yolo_face as O
+    d, wq = det
+    imgs = frames(seed=13, n=4)
+    agree = total = 0
+    for im in imgs:
+        ref = O.regions(im, wq)
+        got = d.regions(im)
+        total += len(ref)
+        for a in ref:
+            for b in got:
+                if all(abs(a[k] - b[k]) <= 2 for k in ("x", "y", "w", "h")) and abs(a["confidence"] - b["confidence"]) <= 0.02 \
+                        and all(abs(p - q) <= 2 for p, q in zip(a["left_eye"] + a["right_eye"], b["left_eye"] + b["right_eye"])):
+                    agree += 1
+                    break
+        assert abs(len(ref) - len(got)) <= max(1, len(ref) // 10)
+    assert total >= 4 and agree >= 0.9 * total, f"{agree} of {total} regions agree"
+
+
+def test_extract_faces_entries_and_errors(det, gpu_ctx):
+    from frhot import FrhotError
+    d, _wq = det
+    im = frames(seed=13, n=1)[0]
+    faces = d.extract_faces(im, expand_percentage=10)
+    for f in faces:
+        a = f["facial_area"]
+        assert f["is_real"] is None and 0 <= a["x"] and a["x"] + a["w"] <= im.shape[1] and a["y"] + a["h"] <= im.shape[0]
+        assert f["face"].shape[:2] == (a["h"], a["w"])
+    with pytest.raises(FrhotError):
+        d.detect([im] * 2, conf=1.5)
+    with pytest.raises(FrhotError):
+        d.debug_read("nope", 1, 1, 1, 16)
+    assert d.detect([im] * 5)[4].shape == d.detect([im])[0].shape          # more frames than max_batch: several calls
