@@ -2103,6 +2103,9 @@ int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int3
     }
     HIP_TRY(hipMemcpyAsync(d->img_dev, d->img_pin, total, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d->meta_dev, meta.data(), sizeof(DetImageMeta) * B, hipMemcpyHostToDevice, s));
+    // (Replaying the letterbox and the ~110 launches of the forward pass from a captured graph was
+    // measured: 1.68 -> 1.62 ms for one frame.  The small maps' kernels are bound by their own serial
+    // K loops on a handful of blocks, not by launch gaps, so the launches stay plain.)
     HIP_TRY(launch_det_letterbox(d->img_dev, d->meta_dev, d->t.at("in").p, B, s));
     int rc = det_forward_enqueue(d, B);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }

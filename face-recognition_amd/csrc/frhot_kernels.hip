@@ -3385,18 +3385,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const half_t* __restr
 // are a few KiB to 1 MiB and stay in L2; no LDS).
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-template <int KS, int ST>
+// KD: input channels per MFMA (32: v_mfma_f32_16x16x32_f16 with 16-byte operand loads, for layers whose
+// channel count allows it; 16: the x16 form with 8-byte loads).  PG: groups of 16 pixels per wave
+// (4 for the large maps: every weight fragment then feeds four MFMAs; 2 keeps more waves busy on the
+// 20 x 20 and 40 x 40 maps of a small batch).
+template <int KS, int ST, int KD, int PG>
 __global__ __launch_bounds__(256) void det_conv_kernel(DetConv d, int M) {
+    typedef _Float16 frag_t __attribute__((ext_vector_type(KD / 4)));
+    constexpr int KL = KD / 4;          // halfs per lane and MFMA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * 64;
     const int nsub = (d.cout - n0) / 16 < 4 ? (d.cout - n0) / 16 : 4;
-    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    const int m0 = (blockIdx.x * 4 + wave) * (16 * PG);
     if (m0 >= M) return;
     const int HWo = d.Ho * d.Wo;
-    int pb[2], py[2], px[2];
-    bool pv[2];
+    int pb[PG], py[PG], px[PG];
+    bool pv[PG];
 #pragma unroll
-    for (int pg = 0; pg < 2; ++pg) {
+    for (int pg = 0; pg < PG; ++pg) {
         const int m = m0 + pg * 16 + l15;
         pv[pg] = m < M;
         const int mm = pv[pg] ? m : M - 1;
@@ -3405,49 +3411,56 @@ __global__ __launch_bounds__(256) void det_conv_kernel(DetConv d, int M) {
         py[pg] = rem / d.Wo;
         px[pg] = rem - py[pg] * d.Wo;
     }
-    float4v acc[4][2];
+    float4v acc[4][PG];
 #pragma unroll
     for (int ns = 0; ns < 4; ++ns)
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg) acc[ns][pg] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int pg = 0; pg < PG; ++pg) acc[ns][pg] = float4v{0.f, 0.f, 0.f, 0.f};
     const long wrow = (long)KS * KS * d.cin;            // halfs per output channel
-    const half4v zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    frag_t zero;
+#pragma unroll
+    for (int e = 0; e < KL; ++e) zero[e] = (half_t)0.f;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            const half_t* xp[2];
-            bool ok[2];
+            const half_t* xp[PG];
+            bool ok[PG];
 #pragma unroll
-            for (int pg = 0; pg < 2; ++pg) {
+            for (int pg = 0; pg < PG; ++pg) {
                 const int iy = py[pg] * ST + ky - KS / 2, ix = px[pg] * ST + kx - KS / 2;
                 ok[pg] = pv[pg] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
                 const int cy = ok[pg] ? iy : 0, cx = ok[pg] ? ix : 0;
-                xp[pg] = d.x + (((long)pb[pg] * d.H + cy) * d.W + cx) * d.xc + d.xc0 + 4 * g;
+                xp[pg] = d.x + (((long)pb[pg] * d.H + cy) * d.W + cx) * d.xc + d.xc0 + KL * g;
             }
-            const half_t* wp = d.w + ((long)(n0 + l15) * KS * KS + ky * KS + kx) * d.cin + 4 * g;
-            for (int cg = 0; cg < d.cin; cg += 16) {
-                half4v bf[2];
+            const half_t* wp = d.w + ((long)(n0 + l15) * KS * KS + ky * KS + kx) * d.cin + KL * g;
+            for (int cg = 0; cg < d.cin; cg += KD) {
+                frag_t bf[PG];
 #pragma unroll
-                for (int pg = 0; pg < 2; ++pg) bf[pg] = ok[pg] ? *(const half4v*)(xp[pg] + cg) : zero4;
+                for (int pg = 0; pg < PG; ++pg) bf[pg] = ok[pg] ? *(const frag_t*)(xp[pg] + cg) : zero;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
                     if (ns < nsub) {
-                        const half4v af = *(const half4v*)(wp + ns * 16 * wrow + cg);
+                        const frag_t af = *(const frag_t*)(wp + ns * 16 * wrow + cg);
 #pragma unroll
-                        for (int pg = 0; pg < 2; ++pg)
-                            acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x16f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
+                        for (int pg = 0; pg < PG; ++pg) {
+                            if constexpr (KD == 32)
+                                acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
+                            else
+                                acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x16f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+    const half4v zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 #pragma unroll
     for (int ns = 0; ns < 4; ++ns) {
         if (ns >= nsub) continue;
         const int n = n0 + ns * 16 + 4 * g;
         const float4v bv = *(const float4v*)(d.b + n);
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg) {
+        for (int pg = 0; pg < PG; ++pg) {
             if (!pv[pg]) continue;
             const long pix = ((long)pb[pg] * d.Ho + py[pg]) * d.Wo + px[pg];
             half4v o;
@@ -3887,11 +3900,23 @@ hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
     if ((d.xc0 | d.yc0 | d.xc | d.yc) % 4 || (d.r && (d.rc0 | d.rc) % 4)) return hipErrorInvalidValue;   // 8-byte accesses
     const long M = (long)B * d.Ho * d.Wo;
     if (M <= 0 || M > 0x7fffffffL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((d.cout + 63) / 64));
-    if (d.k == 3 && d.stride == 1) hipLaunchKernelGGL((det_conv_kernel<3, 1>), grid, dim3(256), 0, s, d, (int)M);
-    else if (d.k == 3 && d.stride == 2) hipLaunchKernelGGL((det_conv_kernel<3, 2>), grid, dim3(256), 0, s, d, (int)M);
-    else if (d.k == 1 && d.stride == 1) hipLaunchKernelGGL((det_conv_kernel<1, 1>), grid, dim3(256), 0, s, d, (int)M);
+    // 16-byte operand loads need the slices' first channels and widths to be multiples of 8
+    const bool k32 = d.cin % 32 == 0 && d.xc0 % 8 == 0 && d.xc % 8 == 0;
+    const bool big = M >= 4 * 64 * 256;                 // enough pixels for a block per CU at 64 per wave
+    const int ppb = big ? 256 : 128;                    // pixels per block
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)((d.cout + 63) / 64));
+#define FR_DETC(KS, ST)                                                                                         \
+    do {                                                                                                        \
+        if (k32 && big) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 32, 4>), grid, dim3(256), 0, s, d, (int)M);  \
+        else if (k32) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 32, 2>), grid, dim3(256), 0, s, d, (int)M);    \
+        else if (big) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 16, 4>), grid, dim3(256), 0, s, d, (int)M);    \
+        else hipLaunchKernelGGL((det_conv_kernel<KS, ST, 16, 2>), grid, dim3(256), 0, s, d, (int)M);             \
+    } while (0)
+    if (d.k == 3 && d.stride == 1) FR_DETC(3, 1);
+    else if (d.k == 3 && d.stride == 2) FR_DETC(3, 2);
+    else if (d.k == 1 && d.stride == 1) FR_DETC(1, 1);
     else return hipErrorInvalidValue;
+#undef FR_DETC
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
