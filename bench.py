@@ -61,6 +61,7 @@ def parse():
                     "it shares its kernel with the headline scan)")
     ap.add_argument("--no-scan-extra", action="store_true", help="skip the rank8 and 10m_q64 scan-only shapes "
                     "(profiling passes: they share kernels with other workloads)")
+    ap.add_argument("--no-detector", action="store_true", help="skip the face detector's throughput measurement")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive (host crops in) measurement")
     ap.add_argument("--scan-shape-only", choices=sorted(SCAN_SHAPES), default=None,
                     help="run only this scan-only shape, a few launches, and print its object (counter passes: "
@@ -268,6 +269,31 @@ def pmc_traffic(rows, dim, queries, k):
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')} rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def detector_leg(ctx, args):
+    """The face detector in front of the recognition path (not part of `value`): 32 frames of 480 x 640 as
+    host arrays through frhot_det_detect (letterbox, YOLOv8n-pose forward, decode, suppression), random
+    weights of the architecture, host wall clock."""
+    from frhot import detector as D
+    from frhot import synth
+    nb = 32
+    det = D.Detector(ctx, D.pack_blob(D.synthetic_weights(3)), max_batch=nb)
+    try:
+        frames = [np.ascontiguousarray(f[:480, :640]) for f in synth.crops(seed=args.seed + 31, n=nb, lo=640, hi=700)]
+        for _ in range(2):
+            det.detect(frames)
+        n_it = 10
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            det.detect(frames)
+        dt = (time.perf_counter() - t0) / n_it
+    finally:
+        det.close()
+    tf = 2.0 * D.MACS_PER_FRAME * nb / dt / 1e12
+    return {"what": "frhot_det_detect: 32 host frames of 480x640 -> face regions (YOLOv8n-pose layout, random weights)",
+            "frames_per_s": nb / dt, "ms_per_call": dt * 1e3, "frames": nb, "gflop_per_frame": 2.0 * D.MACS_PER_FRAME / 1e9,
+            "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
 
 
 def main():
@@ -571,6 +597,9 @@ def main():
                     line["search_inside_collections"] = keyed
             if blur_leg is not None:
                 line["blur_gate"] = blur_leg
+            if P == 1 and not rehearse and not args.no_detector:
+                log("detector")
+                line["detector"] = detector_leg(ctx, args)
             if P == 1 and not rehearse and not args.no_cpu_baseline:
                 log("cpu baseline")
                 base, gates = cpu_baseline(ctx, gal, images, args, rows_local, blur_sums)

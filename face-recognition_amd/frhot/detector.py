@@ -211,6 +211,23 @@ class Detector:
         return out
 
 
+    def as_extract_faces(self, expand_percentage: int = 10, anti_spoof=None, assume_real: bool = False):
+        """The callable frhot.quality.install_models(extract_faces=...) takes, i.e. what the reference's
+        detect_face and anti-spoofing pass call (legacy.py:60-65,80-86).  DeepFace judges every face
+        with a second network; that network is not part of this package, so the verdict comes from
+        `anti_spoof(face crop) -> bool` if one is given, and is True for every face only when the
+        operator says so with `assume_real=True`."""
+        if anti_spoof is None and not assume_real:
+            raise ValueError("no anti-spoofing model: pass anti_spoof=callable, or assume_real=True to accept every face")
+
+        def run(image):
+            faces = self.extract_faces(np.ascontiguousarray(image), expand_percentage)
+            for f in faces:
+                f["is_real"] = bool(anti_spoof(f["face"])) if anti_spoof is not None else True
+            return faces
+        return run
+
+
 def region_of(row) -> dict:
     """One detect() row -> DeepFace's facial area: the box through its centre form
     (x = int(cx - w / 2), w = int(w)), keypoint 0 as the right eye and 1 as the left eye, as ints."""

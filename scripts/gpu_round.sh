@@ -14,8 +14,8 @@ tail -1 "$out/smoke.log"
 timeout -k 10 400 python -u bench.py > "$out/bench.json" 2> "$out/bench.err" || { tail -30 "$out/bench.err"; exit 1; }
 cat "$out/bench.json"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 --no-scan-extra > "$out/trace.log" 2>&1 || { tail -30 "$out/trace.log"; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 --no-scan-extra > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 --no-scan-extra > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 --no-scan-extra --no-detector > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-leg --no-scan4096 --no-scan-extra --no-detector > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }
 # the scan-only shapes that share a kernel with another workload: counter passes of their own
 for shape in rank8 10m_q64; do
   for c in FETCH_SIZE WRITE_SIZE; do

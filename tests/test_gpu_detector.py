@@ -140,3 +140,33 @@ def test_extract_faces_entries_and_errors(det, gpu_ctx):
     with pytest.raises(FrhotError):
         d.debug_read("nope", 1, 1, 1, 16)
     assert d.detect([im] * 5)[4].shape == d.detect([im])[0].shape          # more frames than max_batch: several calls
+
+
+def test_frame_to_identity_through_the_detector(det, gpu_ctx):
+    """A frame goes through the GPU detector, the most confident region is cropped, embedded and
+    searched on the same context: the self-contained path of the reference's recognise request
+    (face_service.py:145-150,221-233 with legacy.detect_face in front).  Enrolling the crop of one
+    frame makes that frame's face its own best match."""
+    from frhot import quality
+    from frhot.engine import Gallery
+    d, _wq = det
+    with pytest.raises(ValueError):
+        d.as_extract_faces()
+    quality.install_models(extract_faces=d.as_extract_faces(expand_percentage=10, assume_real=True))
+    try:
+        gal = Gallery(gpu_ctx, 4096, 64)
+        crops = []
+        for i, im in enumerate(frames(seed=21, n=3, lo=400, hi=700)):
+            boxes, scores, distances = quality.detect_face(im)
+            assert len(boxes) >= 1 and len(boxes) == len(scores) == len(distances)
+            assert (np.diff(scores) <= 0).all() and (scores >= quality.CONF_THRESHOLD).all()
+            x, y, w, h = boxes[0]
+            assert w > 0 and h > 0
+            crops.append(np.ascontiguousarray(im[y:y + h, x:x + w]))
+        emb = gpu_ctx.embed(crops, gamma=True)
+        gal.upsert(emb, 0, np.arange(3))
+        s, r, _ = gpu_ctx.recognise(gal, crops, None, 1, gamma=True)
+        assert r[:, 0].tolist() == [0, 1, 2] and (s[:, 0] > 0.999).all()
+        gal.close()
+    finally:
+        quality.install_models()
