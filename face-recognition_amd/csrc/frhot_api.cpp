@@ -1800,11 +1800,10 @@ struct frhot_detector {
     std::vector<void*> owned;                       // every device allocation of the detector
     std::unordered_map<std::string, DetTensor> t;   // named tensors (also what frhot_det_debug_read serves)
     DetImageMeta* meta_dev = nullptr;
-    uint8_t* img_dev = nullptr; size_t img_cap = 0;
-    uint8_t* img_pin = nullptr; size_t img_pin_cap = 0;
     DetCand* cand_dev = nullptr; int* count_dev = nullptr;
     DetCand* cand_pin = nullptr; int* count_pin = nullptr;
     static constexpr int kCap = 2048;               // candidates kept per image before suppression
+    std::mutex dmu;                                 // one detect call at a time (the activation tensors are the detector's)
 };
 
 namespace {
@@ -1972,7 +1971,7 @@ int frhot_det_create(frhot_ctx* c, const void* blob_v, size_t nbytes, int max_ba
     d->ctx = c; d->max_batch = max_batch;
     struct Cleanup {
         std::unique_ptr<frhot_detector>& d; bool armed = true;
-        ~Cleanup() { if (armed && d) { for (void* p : d->owned) (void)hipFree(p); if (d->img_pin) (void)hipHostFree(d->img_pin);
+        ~Cleanup() { if (armed && d) { for (void* p : d->owned) (void)hipFree(p);
                                        if (d->cand_pin) (void)hipHostFree(d->cand_pin); if (d->count_pin) (void)hipHostFree(d->count_pin); } }
     } cleanup{d};
     const uint8_t* blob = (const uint8_t*)blob_v;
@@ -2048,8 +2047,6 @@ int frhot_det_destroy(frhot_detector* d) {
         DeviceGuard dg(d->ctx->device);
         (void)hipStreamSynchronize(d->ctx->stream);
         for (void* p : d->owned) (void)hipFree(p);
-        if (d->img_dev) (void)hipFree(d->img_dev);
-        if (d->img_pin) (void)hipHostFree(d->img_pin);
         if (d->cand_pin) (void)hipHostFree(d->cand_pin);
         if (d->count_pin) (void)hipHostFree(d->count_pin);
     }
@@ -2066,14 +2063,20 @@ int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int3
     if (max_faces <= 0 || max_faces > 300) return fail(FRHOT_EINVAL, "max_faces %d outside 1..300", max_faces);
     if (!(conf > 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return fail(FRHOT_EINVAL, "conf %g / iou %g out of range", conf, iou);
     frhot_ctx* c = d->ctx;
+    std::lock_guard<std::mutex> dlk(d->dmu);
+    // the frames go through one of the context's staging slots: packed by a few host threads into its
+    // page-locked mirror and uploaded in pieces on the copy stream, like the crops of frhot_embed
+    DeviceGuard dg(c->device);
+    SlotLease lease(c);
+    frhot_ctx::Slot& sl = lease.sl;
+    CropStaging st(c, sl);
+    int rc = st.begin(images, hw, strides, B, 0);
+    if (rc) return rc;
     std::vector<DetImageMeta> meta(B);
-    size_t total = 0;
     for (int i = 0; i < B; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
-        if (h <= 0 || w <= 0 || h > 16384 || w > 16384 || strides[i] < 3 * w || !images[i])
-            return fail(FRHOT_EINVAL, "bad image %d: %dx%d stride %d", i, h, w, strides[i]);
         DetImageMeta& m = meta[i];
-        m.offset = (int64_t)total; m.h = h; m.w = w; m.stride = 3 * w;
+        m.offset = st.offsets[i]; m.h = h; m.w = w; m.stride = st.packed_strides[i];
         // ratio and new size as ultralytics' LetterBox computes them (float64, Python round = half to even)
         const double r = std::min(640.0 / h, 640.0 / w);
         m.nw = (int)std::nearbyint(w * r); m.nh = (int)std::nearbyint(h * r);
@@ -2081,33 +2084,17 @@ int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int3
         const double dw = (640 - m.nw) / 2.0, dh = (640 - m.nh) / 2.0;
         m.top = (int)std::nearbyint(dh - 0.1); m.left = (int)std::nearbyint(dw - 0.1);
         m.sy = (double)h / m.nh; m.sx = (double)w / m.nw;
-        total += ((size_t)h * 3 * w + 15) & ~(size_t)15;
     }
-    std::lock_guard<std::mutex> lk(c->mu);
-    DeviceGuard dg(c->device);
+    // the context's lock is held to enqueue only; the wait for the answer leaves it to other callers
+    std::unique_lock<std::mutex> lk(c->mu);
     hipStream_t s = c->stream;
-    if (total > d->img_cap) {
-        HIP_TRY(hipStreamSynchronize(s));
-        if (d->img_dev) { HIP_TRY(hipFree(d->img_dev)); d->img_dev = nullptr; d->img_cap = 0; }
-        if (d->img_pin) { HIP_TRY(hipHostFree(d->img_pin)); d->img_pin = nullptr; }
-        const size_t cap = total + total / 4 + 4096;
-        HIP_TRY(hipMalloc((void**)&d->img_dev, cap));
-        HIP_TRY(hipHostMalloc((void**)&d->img_pin, cap, hipHostMallocDefault));
-        d->img_cap = cap;
-    }
-    for (int i = 0; i < B; ++i) {
-        const size_t h = (size_t)hw[2 * i], row = (size_t)3 * hw[2 * i + 1];
-        uint8_t* dst = d->img_pin + meta[i].offset;
-        if ((size_t)strides[i] == row) memcpy(dst, images[i], h * row);
-        else for (size_t y = 0; y < h; ++y) memcpy(dst + y * row, images[i] + y * (size_t)strides[i], row);
-    }
-    HIP_TRY(hipMemcpyAsync(d->img_dev, d->img_pin, total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
     HIP_TRY(hipMemcpyAsync(d->meta_dev, meta.data(), sizeof(DetImageMeta) * B, hipMemcpyHostToDevice, s));
     // (Replaying the letterbox and the ~110 launches of the forward pass from a captured graph was
     // measured: 1.68 -> 1.62 ms for one frame.  The small maps' kernels are bound by their own serial
     // K loops on a handful of blocks, not by launch gaps, so the launches stay plain.)
-    HIP_TRY(launch_det_letterbox(d->img_dev, d->meta_dev, d->t.at("in").p, B, s));
-    int rc = det_forward_enqueue(d, B);
+    HIP_TRY(launch_det_letterbox(sl.dev, d->meta_dev, d->t.at("in").p, B, s));
+    rc = det_forward_enqueue(d, B);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     DetHead heads[3];
     static const int strides_l[3] = {8, 16, 32};
@@ -2120,15 +2107,25 @@ int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int3
     }
     HIP_TRY(launch_det_decode(heads, conf, d->cand_dev, d->count_dev, frhot_detector::kCap, B, s));
     HIP_TRY(hipMemcpyAsync(d->count_pin, d->count_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    // the survivors of every image, then suppression and the way back to the frame, on the host (a handful of boxes)
+    HIP_TRY(hipEventRecord(sl.done, s));
+    lk.unlock();
+    HIP_TRY(hipEventSynchronize(sl.done));
+    // the survivors of every image (their number is known only now), then suppression and the way back
+    // to the frame on the host: a handful of boxes
+    for (int i = 0; i < B; ++i)
+        if (d->count_pin[i] > frhot_detector::kCap)
+            return fail(FRHOT_ECAPACITY, "image %d: %d anchors above the confidence threshold (at most %d are kept)", i,
+                        d->count_pin[i], frhot_detector::kCap);
+    lk.lock();
+    for (int i = 0; i < B; ++i)
+        if (d->count_pin[i] > 0)
+            HIP_TRY(hipMemcpyAsync(d->cand_pin + (size_t)i * frhot_detector::kCap, d->cand_dev + (size_t)i * frhot_detector::kCap,
+                                   sizeof(DetCand) * d->count_pin[i], hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(sl.done, s));
+    lk.unlock();
+    HIP_TRY(hipEventSynchronize(sl.done));
     for (int i = 0; i < B; ++i) {
-        int n = d->count_pin[i];
-        if (n > frhot_detector::kCap)
-            return fail(FRHOT_ECAPACITY, "image %d: %d anchors above the confidence threshold (at most %d are kept)", i, n, frhot_detector::kCap);
-        if (n > 0)
-            HIP_TRY(hipMemcpy(d->cand_pin + (size_t)i * frhot_detector::kCap, d->cand_dev + (size_t)i * frhot_detector::kCap,
-                              sizeof(DetCand) * n, hipMemcpyDeviceToHost));
+        const int n = d->count_pin[i];
         const DetCand* cand = d->cand_pin + (size_t)i * frhot_detector::kCap;
         std::vector<int> order(n);
         for (int j = 0; j < n; ++j) order[j] = j;
