@@ -1800,6 +1800,7 @@ struct frhot_detector {
     std::vector<void*> owned;                       // every device allocation of the detector
     std::unordered_map<std::string, DetTensor> t;   // named tensors (also what frhot_det_debug_read serves)
     DetImageMeta* meta_dev = nullptr;
+    _Float16* zeros = nullptr;                      // 4 KiB: the input of a tap outside the image
     DetCand* cand_dev = nullptr; int* count_dev = nullptr;
     DetCand* cand_pin = nullptr; int* count_pin = nullptr;
     static constexpr int kCap = 2048;               // candidates kept per image before suppression
@@ -1864,6 +1865,7 @@ struct DetRun {
         c.w = (const _Float16*)L.w; c.b = L.b;
         c.y = out.t->p; c.Ho = out.t->h; c.Wo = out.t->w; c.yc = out.t->c; c.yc0 = out.c0; c.cout = out.c;
         if (res) { c.r = res->t->p; c.rc = res->t->c; c.rc0 = res->c0; }
+        c.zeros = d->zeros;
         c.k = L.k; c.stride = stride; c.act = act ? 1 : 0;
         if ((in.t->h + stride - 1) / stride != out.t->h || (in.t->w + stride - 1) / stride != out.t->w)
             return fail(FRHOT_ESTATE, "detector graph: %s maps %dx%d to %dx%d at stride %d", layer, in.t->h, in.t->w, out.t->h, out.t->w, stride);
@@ -2027,7 +2029,9 @@ int frhot_det_create(frhot_ctx* c, const void* blob_v, size_t nbytes, int max_ba
         snprintf(n, sizeof n, "kpt%d", l); T(n, fhw[l], 16);
     }
     if (rc) return rc;
-    rc = det_alloc(d.get(), (void**)&d->meta_dev, sizeof(DetImageMeta) * max_batch);
+    rc = det_alloc(d.get(), (void**)&d->zeros, 4096);
+    if (!rc) HIP_TRY(hipMemset(d->zeros, 0, 4096));
+    if (!rc) rc = det_alloc(d.get(), (void**)&d->meta_dev, sizeof(DetImageMeta) * max_batch);
     if (!rc) rc = det_alloc(d.get(), (void**)&d->cand_dev, sizeof(DetCand) * (size_t)max_batch * frhot_detector::kCap);
     if (!rc) rc = det_alloc(d.get(), (void**)&d->count_dev, sizeof(int) * max_batch);
     if (rc) return rc;

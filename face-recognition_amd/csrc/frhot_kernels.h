@@ -53,6 +53,7 @@ struct DetConv {
     const _Float16* w; const float* b;               // [cout][k][k][cin] fp16, [cout] fp32 (cout % 16 == 0)
     _Float16* y; int Ho, Wo, yc, yc0, cout;          // output [B,Ho,Wo,yc], channels yc0 .. yc0+cout
     const _Float16* r; int rc, rc0;                  // residual slice (output geometry) added after the activation, or null
+    const _Float16* zeros;                           // 4 KiB of zeros: what a tap outside the image reads
     int k, stride, act;                              // k in {1,3}, stride in {1,2} (k=1: stride 1), act: SiLU
 };
 struct DetImageMeta {

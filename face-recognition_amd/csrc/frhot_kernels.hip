@@ -3388,14 +3388,16 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 // KD: input channels per MFMA (32: v_mfma_f32_16x16x32_f16 with 16-byte operand loads, for layers whose
 // channel count allows it; 16: the x16 form with 8-byte loads).  PG: groups of 16 pixels per wave
 // (4 for the large maps: every weight fragment then feeds four MFMAs; 2 keeps more waves busy on the
-// 20 x 20 and 40 x 40 maps of a small batch).
-template <int KS, int ST, int KD, int PG>
+// 20 x 20 and 40 x 40 maps of a small batch).  NS: groups of 16 output channels per wave.
+// The K loop runs over (tap, channel chunk) steps as ONE software-pipelined sequence: the operands
+// of step s+1 are loaded before the MFMAs of step s issue, and nothing in it branches (a tap that
+// falls outside the image reads a page of zeros instead of being skipped).
+template <int KS, int ST, int KD, int PG, int NS>
 __global__ __launch_bounds__(256) void det_conv_kernel(DetConv d, int M) {
     typedef _Float16 frag_t __attribute__((ext_vector_type(KD / 4)));
     constexpr int KL = KD / 4;          // halfs per lane and MFMA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.y * 64;
-    const int nsub = (d.cout - n0) / 16 < 4 ? (d.cout - n0) / 16 : 4;
+    const int n0 = blockIdx.y * (16 * NS);
     const int m0 = (blockIdx.x * 4 + wave) * (16 * PG);
     if (m0 >= M) return;
     const int HWo = d.Ho * d.Wo;
@@ -3411,52 +3413,63 @@ __global__ __launch_bounds__(256) void det_conv_kernel(DetConv d, int M) {
         py[pg] = rem / d.Wo;
         px[pg] = rem - py[pg] * d.Wo;
     }
-    float4v acc[4][PG];
+    float4v acc[NS][PG];
 #pragma unroll
-    for (int ns = 0; ns < 4; ++ns)
+    for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) acc[ns][pg] = float4v{0.f, 0.f, 0.f, 0.f};
     const long wrow = (long)KS * KS * d.cin;            // halfs per output channel
-    frag_t zero;
+    const half_t* const wbase = d.w + (long)(n0 + l15) * wrow + KL * g;
+    const half_t* xp[PG];
+    auto tap_setup = [&](int tap) __attribute__((always_inline)) {
+        const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
-    for (int e = 0; e < KL; ++e) zero[e] = (half_t)0.f;
+        for (int pg = 0; pg < PG; ++pg) {
+            const int iy = py[pg] * ST + ky - KS / 2, ix = px[pg] * ST + kx - KS / 2;
+            const bool ok = pv[pg] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            const half_t* real = d.x + (((long)pb[pg] * d.H + iy) * d.W + ix) * d.xc + d.xc0;
+            xp[pg] = (ok ? real : d.zeros) + KL * g;
+        }
+    };
+    frag_t fa[2][NS], fb[2][PG];
+    int tap = 0, cg = 0;
+    auto load = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky)
+        for (int pg = 0; pg < PG; ++pg) fb[buf][pg] = *(const frag_t*)(xp[pg] + cg);
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const half_t* xp[PG];
-            bool ok[PG];
+        for (int ns = 0; ns < NS; ++ns) fa[buf][ns] = *(const frag_t*)(wbase + ns * 16 * wrow + tap * d.cin + cg);
+        cg += KD;
+        if (cg == d.cin) {
+            cg = 0;
+            ++tap;
+            if (tap < KS * KS) tap_setup(tap);
+        }
+    };
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
             for (int pg = 0; pg < PG; ++pg) {
-                const int iy = py[pg] * ST + ky - KS / 2, ix = px[pg] * ST + kx - KS / 2;
-                ok[pg] = pv[pg] && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-                const int cy = ok[pg] ? iy : 0, cx = ok[pg] ? ix : 0;
-                xp[pg] = d.x + (((long)pb[pg] * d.H + cy) * d.W + cx) * d.xc + d.xc0 + KL * g;
+                if constexpr (KD == 32)
+                    acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][ns], fb[buf][pg], acc[ns][pg], 0, 0, 0);
+                else
+                    acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x16f16(fa[buf][ns], fb[buf][pg], acc[ns][pg], 0, 0, 0);
             }
-            const half_t* wp = d.w + ((long)(n0 + l15) * KS * KS + ky * KS + kx) * d.cin + KL * g;
-            for (int cg = 0; cg < d.cin; cg += KD) {
-                frag_t bf[PG];
-#pragma unroll
-                for (int pg = 0; pg < PG; ++pg) bf[pg] = ok[pg] ? *(const frag_t*)(xp[pg] + cg) : zero;
-#pragma unroll
-                for (int ns = 0; ns < 4; ++ns) {
-                    if (ns < nsub) {
-                        const frag_t af = *(const frag_t*)(wp + ns * 16 * wrow + cg);
-#pragma unroll
-                        for (int pg = 0; pg < PG; ++pg) {
-                            if constexpr (KD == 32)
-                                acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
-                            else
-                                acc[ns][pg] = __builtin_amdgcn_mfma_f32_16x16x16f16(af, bf[pg], acc[ns][pg], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+    };
+    const int nsteps = KS * KS * (d.cin / KD);
+    tap_setup(0);
+    load(0);
+    for (int s = 0; s < nsteps; s += 2) {
+        if (s + 1 < nsteps) load(1);
+        mma(0);
+        if (s + 1 < nsteps) {
+            if (s + 2 < nsteps) load(0);
+            mma(1);
         }
+    }
     const half4v zero4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
 #pragma unroll
-    for (int ns = 0; ns < 4; ++ns) {
-        if (ns >= nsub) continue;
+    for (int ns = 0; ns < NS; ++ns) {
         const int n = n0 + ns * 16 + 4 * g;
         const float4v bv = *(const float4v*)(d.b + n);
 #pragma unroll
@@ -3895,7 +3908,7 @@ hipError_t launch_f32_to_unit_f16(const float* q, void* o, int Bq, int D, hipStr
 
 // ---- face detector ----
 hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
-    if (B <= 0 || !d.x || !d.w || !d.b || !d.y || d.cin % 16 || d.cout % 16 || d.cin <= 0 || d.cout <= 0)
+    if (B <= 0 || !d.x || !d.w || !d.b || !d.y || !d.zeros || d.cin % 16 || d.cout % 16 || d.cin <= 0 || d.cout <= 0 || d.cin > 2048)
         return hipErrorInvalidValue;
     if ((d.xc0 | d.yc0 | d.xc | d.yc) % 4 || (d.r && (d.rc0 | d.rc) % 4)) return hipErrorInvalidValue;   // 8-byte accesses
     const long M = (long)B * d.Ho * d.Wo;
@@ -3904,19 +3917,29 @@ hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
     const bool k32 = d.cin % 32 == 0 && d.xc0 % 8 == 0 && d.xc % 8 == 0;
     const bool big = M >= 4 * 64 * 256;                 // enough pixels for a block per CU at 64 per wave
     const int ppb = big ? 256 : 128;                    // pixels per block
-    const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)((d.cout + 63) / 64));
-#define FR_DETC(KS, ST)                                                                                         \
-    do {                                                                                                        \
-        if (k32 && big) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 32, 4>), grid, dim3(256), 0, s, d, (int)M);  \
-        else if (k32) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 32, 2>), grid, dim3(256), 0, s, d, (int)M);    \
-        else if (big) hipLaunchKernelGGL((det_conv_kernel<KS, ST, 16, 4>), grid, dim3(256), 0, s, d, (int)M);    \
-        else hipLaunchKernelGGL((det_conv_kernel<KS, ST, 16, 2>), grid, dim3(256), 0, s, d, (int)M);             \
+    const int ns = d.cout >= 64 ? 4 : d.cout / 16;      // 16, 32 or 48 channels: one block column of that width
+    if (d.cout > 64 && d.cout % 64) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)((d.cout + 16 * ns - 1) / (16 * ns)));
+#define FR_DETN(KS, ST, KD, PG)                                                                                       \
+    do {                                                                                                              \
+        if (ns == 4) hipLaunchKernelGGL((det_conv_kernel<KS, ST, KD, PG, 4>), grid, dim3(256), 0, s, d, (int)M);       \
+        else if (ns == 3) hipLaunchKernelGGL((det_conv_kernel<KS, ST, KD, PG, 3>), grid, dim3(256), 0, s, d, (int)M);  \
+        else if (ns == 2) hipLaunchKernelGGL((det_conv_kernel<KS, ST, KD, PG, 2>), grid, dim3(256), 0, s, d, (int)M);  \
+        else hipLaunchKernelGGL((det_conv_kernel<KS, ST, KD, PG, 1>), grid, dim3(256), 0, s, d, (int)M);               \
+    } while (0)
+#define FR_DETC(KS, ST)                                  \
+    do {                                                 \
+        if (k32 && big) FR_DETN(KS, ST, 32, 4);          \
+        else if (k32) FR_DETN(KS, ST, 32, 2);            \
+        else if (big) FR_DETN(KS, ST, 16, 4);            \
+        else FR_DETN(KS, ST, 16, 2);                     \
     } while (0)
     if (d.k == 3 && d.stride == 1) FR_DETC(3, 1);
     else if (d.k == 3 && d.stride == 2) FR_DETC(3, 2);
     else if (d.k == 1 && d.stride == 1) FR_DETC(1, 1);
     else return hipErrorInvalidValue;
 #undef FR_DETC
+#undef FR_DETN
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
