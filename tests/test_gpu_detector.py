@@ -170,3 +170,44 @@ def test_frame_to_identity_through_the_detector(det, gpu_ctx):
         gal.close()
     finally:
         quality.install_models()
+
+
+def test_detect_and_recognise_from_two_threads(det, gpu_ctx):
+    """Detector calls and fused recognitions arrive from different threads on one context (the
+    reference's handlers run in a thread pool, face_service.py:43,231-233): both go through the
+    context's two staging slots, and every answer equals the one the same call gives alone."""
+    import threading
+    from frhot import synth
+    from frhot.engine import Gallery
+    d, _wq = det
+    fr = frames(seed=31, n=3)
+    crops = synth.crops(seed=32, n=12, lo=120, hi=300)
+    gal = Gallery(gpu_ctx, 4096, 64)
+    gal.upsert(gpu_ctx.embed(crops), 0, np.arange(12))
+    want_det = d.detect(fr)
+    want_s, want_r, _ = gpu_ctx.recognise(gal, crops, None, 3)
+    errors = []
+
+    def detect_loop():
+        try:
+            for _ in range(6):
+                got = d.detect(fr)
+                assert all(np.array_equal(a, b) for a, b in zip(got, want_det))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    def recognise_loop():
+        try:
+            for _ in range(12):
+                s, r, _ = gpu_ctx.recognise(gal, crops, None, 3)
+                assert np.array_equal(r, want_r) and np.array_equal(s, want_s)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=detect_loop), threading.Thread(target=recognise_loop), threading.Thread(target=recognise_loop)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    gal.close()
+    assert not errors, errors
