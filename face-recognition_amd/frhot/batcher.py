@@ -141,6 +141,60 @@ class EmbedBatcher(_MicroBatcher):
             self.items += len(group)
 
 
+class DetectBatcher(_MicroBatcher):
+    """Groups concurrent single-frame detections (the reference's detect_face and anti-spoofing pass
+    run once per request, legacy.py:60-65,80-86) into one frhot_det_detect call: one frame takes the
+    detector 1.15 ms, eight frames 1.6 ms together."""
+
+    def __init__(self, detector, max_batch: int | None = None, max_delay_s: float = 0.002, conf: float = 0.25):
+        self.detector = detector
+        self.conf = conf
+        super().__init__(min(max_batch or detector.max_batch, detector.max_batch), max_delay_s, "frhot-det-batcher")
+
+    def submit(self, frame: np.ndarray) -> Future:
+        """Queue one uint8 BGR frame; the future resolves to its float32 [n, 20] detections
+        (Detector.detect's rows)."""
+        a = np.asarray(frame)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:       # fails this request only, before it can join a batch
+            fut: Future = Future()
+            fut.set_exception(ValueError(f"frame must be uint8 [h, w, 3], not {a.dtype} {a.shape}"))
+            return fut
+        return self._put(a)
+
+    def detect(self, frame: np.ndarray, timeout: float | None = 60.0) -> np.ndarray:
+        return self.submit(frame).result(timeout=timeout)
+
+    def extract_faces(self, frame, expand_percentage: int = 10, anti_spoof=None, assume_real: bool = False):
+        """Detector.as_extract_faces's entries for one frame, detected as part of a batch."""
+        from .detector import faces_of
+        if anti_spoof is None and not assume_real:
+            raise ValueError("no anti-spoofing model: pass anti_spoof=callable, or assume_real=True to accept every face")
+        frame = np.ascontiguousarray(frame)
+        faces = faces_of(frame, self.detect(frame), expand_percentage)
+        for f in faces:
+            f["is_real"] = bool(anti_spoof(f["face"])) if anti_spoof is not None else True
+        return faces
+
+    def _dispatch(self, batch):
+        try:
+            out = self.detector.detect([b[0] for b in batch], conf=self.conf)
+            for b, rows in zip(batch, out):
+                b[1].set_result(rows)
+            self.batches += 1
+        except Exception as e:
+            if len(batch) == 1:
+                batch[0][1].set_exception(e)
+                self.batches += 1
+            else:       # find the frame(s) the library refuses; every other request still gets its answer
+                for b in batch:
+                    try:
+                        b[1].set_result(self.detector.detect([b[0]], conf=self.conf)[0])
+                    except Exception as e1:
+                        b[1].set_exception(e1)
+                    self.batches += 1
+        self.items += len(batch)
+
+
 class SearchBatcher(_MicroBatcher):
     """Groups concurrent search_point calls into one GalleryService.search_points call."""
 

@@ -196,20 +196,7 @@ class Detector:
     def extract_faces(self, image, expand_percentage: int = 0):
         """The entries DeepFace.extract_faces(detector_backend="yolov8") returns for a frame, without
         the parts named in the module text: `is_real` is None, `face` is the unaligned box crop."""
-        H, W = image.shape[:2]
-        out = []
-        for reg in self.regions(image):
-            x, y, w, h = reg["x"], reg["y"], reg["w"], reg["h"]
-            if expand_percentage > 0:
-                ew, eh = int(w * expand_percentage / 100), int(h * expand_percentage / 100)
-                x, y = max(0, x - ew // 2), max(0, y - eh // 2)
-                w, h = min(W - x, w + ew), min(H - y, h + eh)
-            out.append({"face": image[y:y + h, x:x + w],
-                        "facial_area": {"x": x, "y": y, "w": w, "h": h, "left_eye": reg["left_eye"],
-                                        "right_eye": reg["right_eye"]},
-                        "confidence": round(reg["confidence"], 2), "is_real": None})
-        return out
-
+        return faces_of(image, self.detect([image])[0], expand_percentage)
 
     def as_extract_faces(self, expand_percentage: int = 10, anti_spoof=None, assume_real: bool = False):
         """The callable frhot.quality.install_models(extract_faces=...) takes, i.e. what the reference's
@@ -226,6 +213,24 @@ class Detector:
                 f["is_real"] = bool(anti_spoof(f["face"])) if anti_spoof is not None else True
             return faces
         return run
+
+
+def faces_of(image, rows, expand_percentage: int = 0) -> list:
+    """detect() rows of one frame -> DeepFace.extract_faces entries (facial area enlarged by
+    `expand_percentage` as deepface's detection module does, clipped to the frame)."""
+    H, W = image.shape[:2]
+    out = []
+    for reg in (region_of(row) for row in rows):
+        x, y, w, h = reg["x"], reg["y"], reg["w"], reg["h"]
+        if expand_percentage > 0:
+            ew, eh = int(w * expand_percentage / 100), int(h * expand_percentage / 100)
+            x, y = max(0, x - ew // 2), max(0, y - eh // 2)
+            w, h = min(W - x, w + ew), min(H - y, h + eh)
+        out.append({"face": image[y:y + h, x:x + w],
+                    "facial_area": {"x": x, "y": y, "w": w, "h": h, "left_eye": reg["left_eye"],
+                                    "right_eye": reg["right_eye"]},
+                    "confidence": round(reg["confidence"], 2), "is_real": None})
+    return out
 
 
 def region_of(row) -> dict:

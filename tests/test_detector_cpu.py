@@ -116,3 +116,58 @@ def test_region_of_matches_oracle_rule():
     row[5:11] = (30.9, 50.1, 0.9, 80.2, 51.7, 0.8)
     r = region_of(row)
     assert r == {"x": 10, "y": 20, "w": 100, "h": 120, "right_eye": (30, 50), "left_eye": (80, 51), "confidence": 0.875}
+
+
+def test_detect_batcher_groups_frames_and_isolates_failures():
+    """Concurrent single-frame requests share device calls; a frame the detector refuses fails its own
+    request only; extract_faces needs an anti-spoofing policy."""
+    import threading
+    from frhot.batcher import DetectBatcher
+
+    class FakeDetector:
+        max_batch = 8
+
+        def __init__(self):
+            self.calls = []
+
+        def detect(self, images, conf=0.25):
+            self.calls.append(len(images))
+            if any(im.shape[0] == 13 for im in images):
+                raise RuntimeError("refused")
+            out = []
+            for im in images:
+                row = np.zeros((1, 20), np.float32)
+                row[0, :5] = (1, 2, 1 + im.shape[1] // 2, 2 + im.shape[0] // 2, 0.9)
+                out.append(row)
+            return out
+
+    det = FakeDetector()
+    b = DetectBatcher(det, max_delay_s=0.2)
+    try:
+        frames = [np.zeros((20 + i, 40, 3), np.uint8) for i in range(6)] + [np.zeros((13, 40, 3), np.uint8)]
+        results = [None] * len(frames)
+
+        def run(i):
+            try:
+                results[i] = b.detect(frames[i])
+            except Exception as e:      # noqa: BLE001
+                results[i] = e
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(frames))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert isinstance(results[6], RuntimeError)
+        for i in range(6):
+            assert results[i].shape == (1, 20) and results[i][0, 3] == 2 + (20 + i) // 2
+        assert det.calls[0] > 1, "the first device call carried several frames"
+        with pytest.raises(ValueError):
+            b.detect(np.zeros((4, 4), np.uint8))
+        with pytest.raises(ValueError):
+            b.extract_faces(frames[0])
+        faces = b.extract_faces(frames[0], expand_percentage=10, assume_real=True)
+        assert faces[0]["is_real"] is True and faces[0]["facial_area"]["w"] == 20 + 2 and faces[0]["confidence"] == 0.9
+        faces = b.extract_faces(frames[0], anti_spoof=lambda crop: False)
+        assert faces[0]["is_real"] is False
+    finally:
+        b.close()

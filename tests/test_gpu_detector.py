@@ -211,3 +211,21 @@ def test_detect_and_recognise_from_two_threads(det, gpu_ctx):
         t.join()
     gal.close()
     assert not errors, errors
+
+
+def test_detect_batcher_on_the_gpu(det):
+    """Eight requests in flight share device calls and each gets the rows a lone call gives."""
+    from concurrent.futures import ThreadPoolExecutor
+    from frhot.batcher import DetectBatcher
+    d, _wq = det
+    fr = frames(seed=41, n=8)
+    want = [d.detect([f])[0] for f in fr]
+    b = DetectBatcher(d, max_delay_s=0.05)
+    try:
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            got = list(pool.map(b.detect, fr))
+        assert b.batches < len(fr) and b.items == len(fr)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    finally:
+        b.close()
