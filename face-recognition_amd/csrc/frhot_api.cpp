@@ -1834,12 +1834,13 @@ int det_load_layer(frhot_detector* d, const uint8_t* blob, size_t nbytes, const 
     snprintf(nm, sizeof nm, "%s.b", name);
     const BlobEntry* eb = blob_find(blob, nbytes, nm);
     if (!eb || eb->dtype != 1 || eb->nbytes != (uint64_t)cout * 4) return fail(FRHOT_EINVAL, "detector blob: bad or missing %s", nm);
-    const int cip = (cin + 15) / 16 * 16, cop = (cout + 15) / 16 * 16;
-    std::vector<uint16_t> w((size_t)cop * k * k * cip, 0);
+    const bool first = cin == 3;                    // the first layer: [16][64] with k = tap * 4 + channel (det_conv0_kernel)
+    const int cip = first ? 4 : (cin + 15) / 16 * 16, cop = (cout + 15) / 16 * 16;
+    std::vector<uint16_t> w(first ? (size_t)cop * 64 : (size_t)cop * k * k * cip, 0);
     const uint16_t* src = (const uint16_t*)(blob + ew->offset);
     for (int n = 0; n < cout; ++n)
         for (int t = 0; t < k * k; ++t)
-            memcpy(&w[((size_t)n * k * k + t) * cip], &src[((size_t)n * k * k + t) * cin], (size_t)cin * 2);
+            memcpy(&w[first ? (size_t)n * 64 + t * 4 : ((size_t)n * k * k + t) * cip], &src[((size_t)n * k * k + t) * cin], (size_t)cin * 2);
     std::vector<float> b(cop, 0.f);
     memcpy(b.data(), blob + eb->offset, (size_t)cout * 4);
     DetLayer L; L.k = k; L.cin = cip; L.cout = cop;
@@ -1905,7 +1906,10 @@ struct DetRun {
 int det_forward_enqueue(frhot_detector* d, int B) {
     DetRun r{d, B, d->ctx->stream};
 #define FR_DET(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
-    FR_DET(r.conv("m0", r.all("in"), r.all("m0"), 2, true));
+    {
+        const DetLayer& L0 = d->layers.at("m0");
+        HIP_TRY(launch_det_conv0(d->t.at("in").p, L0.w, L0.b, d->t.at("m0").p, B, d->ctx->stream));
+    }
     FR_DET(r.conv("m1", r.all("m0"), r.all("m1"), 2, true));
     FR_DET(r.c2f("m2", r.all("m1"), "c2", "t2", r.all("m2"), 1, true));
     FR_DET(r.conv("m3", r.all("m2"), r.all("m3"), 2, true));
@@ -2009,7 +2013,7 @@ int frhot_det_create(frhot_ctx* c, const void* blob_v, size_t nbytes, int max_ba
     }
     if (rc) return rc;
     auto T = [&](const char* name, int hw, int ch) { if (!rc) rc = det_tensor(d.get(), name, hw, hw, ch); };
-    T("in", 640, 16); T("m0", 320, 16); T("m1", 160, 32); T("c2", 160, 48); T("t2", 160, 16); T("m2", 160, 32);
+    T("in", 640, 4); T("m0", 320, 16); T("m1", 160, 32); T("c2", 160, 48); T("t2", 160, 16); T("m2", 160, 32);
     T("m3", 80, 64); T("c4", 80, 128); T("t4", 80, 32); T("cat14", 80, 192);
     T("m5", 40, 128); T("c6", 40, 256); T("t6", 40, 64); T("cat11", 40, 384);
     T("m7", 20, 256); T("c8", 20, 384); T("t8", 20, 128); T("m8", 20, 256); T("cat9", 20, 512); T("cat20", 20, 384);

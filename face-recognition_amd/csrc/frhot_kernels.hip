@@ -3537,7 +3537,7 @@ __global__ __launch_bounds__(256) void det_upsample2_kernel(const half_t* __rest
 
 // Letterbox of a BGR frame onto the 640 x 640 canvas: bilinear resize with half-pixel centres
 // (float32, rounded to whole levels as a uint8 resize returns them), 114 outside, RGB order,
-// / 255, written as 16 channels (13 zeros) so that the first convolution is an ordinary one.
+// / 255, written as 4 channels (RGB and a zero), 8 bytes per pixel.
 __global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __restrict__ imgs,
                                                             const DetImageMeta* __restrict__ meta,
                                                             half_t* __restrict__ out) {
@@ -3572,13 +3572,56 @@ __global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __res
         }
         rgb[0] = bgr[2]; rgb[1] = bgr[1]; rgb[2] = bgr[0];
     }
-    half8 lo, hi;
+    half4v o;
+    o[0] = (half_t)(rgb[0] / 255.0f); o[1] = (half_t)(rgb[1] / 255.0f); o[2] = (half_t)(rgb[2] / 255.0f); o[3] = (half_t)0.f;
+    *(half4v*)(out + ((long)b * 640 * 640 + p) * 4) = o;
+}
+
+// The first convolution (3 -> 16 channels, 3 x 3, stride 2) on the 4-channel canvas: K = 9 taps x 4
+// channels = 36, padded to 64, i.e. two 16x16x32 MFMAs per 16 pixels x 16 channels, the pixel operand
+// gathered tap pair by tap pair with 8-byte loads (the same shape as conv1_1 of the descriptor
+// network).  As 16 zero-padded input channels through the generic kernel it was the most expensive
+// launch of the network (0.18 ms per 32 frames) and the canvas four times as large.
+__global__ __launch_bounds__(256) void det_conv0_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w64,
+                                                        const float* __restrict__ bias, half_t* __restrict__ y, int M) {
+    constexpr int H = 640, W = 640, Ho = 320, Wo = 320;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const half8 a0 = *(const half8*)(w64 + l15 * 64 + 8 * g);
+    const half8 a1 = *(const half8*)(w64 + l15 * 64 + 32 + 8 * g);
+    const float4v bv = *(const float4v*)(bias + 4 * g);
+    const half4v z4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    const int t0 = 2 * g, t1 = 2 * g + 1;          // this lane's taps of the first K block; tap 8 (g == 0 only) of the second
+    const int base = (blockIdx.x * 4 + wave) * 64;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { lo[e] = (half_t)0.f; hi[e] = (half_t)0.f; }
-    lo[0] = (half_t)(rgb[0] / 255.0f); lo[1] = (half_t)(rgb[1] / 255.0f); lo[2] = (half_t)(rgb[2] / 255.0f);
-    half_t* o = out + ((long)b * 640 * 640 + p) * 16;
-    *(half8*)o = lo;
-    *(half8*)(o + 8) = hi;
+    for (int pg = 0; pg < 4; ++pg) {
+        const int m = base + pg * 16 + l15;
+        const bool pv = m < M;
+        const int mm = pv ? m : M - 1;
+        const int b = mm / (Ho * Wo), rem = mm - b * (Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const half_t* img = x + (long)b * H * W * 4;
+        auto tap = [&](int t) __attribute__((always_inline)) -> half4v {
+            const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
+            const bool ok = iy >= 0 && ix >= 0;                 // (the far edges stay inside: 2 * 319 + 1 = 639)
+            const half4v v = *(const half4v*)(img + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 4);
+            return ok ? v : z4;
+        };
+        const half4v v0 = tap(t0), v1 = tap(t1), v8 = tap(8);
+        const half_t z = (half_t)0.f;
+        const half8 bf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        half8 bf1 = {v8[0], v8[1], v8[2], v8[3], z, z, z, z};
+        if (g != 0) bf1 = half8{z, z, z, z, z, z, z, z};         // weights are zero beyond k = 35 anyway; keeps NaN-free
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf1, acc, 0, 0, 0);
+        half4v o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = acc[j] + bv[j];
+            o[j] = (half_t)(v / (1.0f + __expf(-v)));
+        }
+        if (pv) *(half4v*)(y + (long)mm * 16 + 4 * g) = o;
+    }
 }
 
 // Head maps of the three levels -> the anchors whose class score exceeds `conf`: xywh on the canvas,
@@ -3940,6 +3983,16 @@ hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
     else return hipErrorInvalidValue;
 #undef FR_DETC
 #undef FR_DETN
+    FR_CHECK_LAUNCH();
+    return hipSuccess;
+}
+
+// x [B,640,640,4] -> y [B,320,320,16]; w64 [16][64] with k = tap * 4 + channel (zero elsewhere)
+hipError_t launch_det_conv0(const void* x, const void* w64, const float* bias, void* y, int B, hipStream_t s) {
+    if (B <= 0 || !x || !w64 || !bias || !y) return hipErrorInvalidValue;
+    const long M = (long)B * 320 * 320;
+    hipLaunchKernelGGL(det_conv0_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const half_t*)x,
+                       (const half_t*)w64, bias, (half_t*)y, (int)M);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

@@ -292,7 +292,7 @@ int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, cons
  * frhot_det_create: blob = the library's weight container ("FRHOTW01") holding, for every
  *   convolution of the network, "<name>.w" fp16 [cout][k][k][cin] with the batch norm folded in and
  *   "<name>.b" fp32 (names: frhot/detector.py, CONVS).  max_batch <= 64 frames per call; the
- *   activations take about 42 MB of device memory per frame.
+ *   activations take about 33 MB of device memory per frame.
  * frhot_det_detect: B BGR uint8 frames given like frhot_embed's crops.  For frame i, counts[i]
  *   faces (at most max_faces <= 300, descending confidence) are written to out[i][j][0..19] =
  *   x1, y1, x2, y2 in frame pixels (clipped to the frame), confidence, then five keypoints as

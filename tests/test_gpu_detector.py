@@ -29,7 +29,7 @@ def test_letterbox_bit_exact(det):
     for i in range(0, len(imgs), 4):
         part = imgs[i:i + 4]
         d.detect(part)
-        got = d.debug_read("in", len(part), 640, 640, 16)
+        got = d.debug_read("in", len(part), 640, 640, 4)
         for j, im in enumerate(part):
             want = O.letterbox(im)[0].astype(np.float16)
             assert np.array_equal(got[j, :, :, :3], want), f"image {i + j} {im.shape}"
