@@ -290,9 +290,10 @@ def detector_leg(ctx, args):
         dt = (time.perf_counter() - t0) / n_it
     finally:
         det.close()
-    tf = 2.0 * D.MACS_PER_FRAME * nb / dt / 1e12
+    tf = 2.0 * D.macs_for(480, 640) * nb / dt / 1e12
     return {"what": "frhot_det_detect: 32 host frames of 480x640 -> face regions (YOLOv8n-pose layout, random weights)",
-            "frames_per_s": nb / dt, "ms_per_call": dt * 1e3, "frames": nb, "gflop_per_frame": 2.0 * D.MACS_PER_FRAME / 1e9,
+            "frames_per_s": nb / dt, "ms_per_call": dt * 1e3, "frames": nb, "canvas": list(D.canvas_of(480, 640)),
+            "gflop_per_frame": 2.0 * D.macs_for(480, 640) / 1e9,
             "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS}
 
 

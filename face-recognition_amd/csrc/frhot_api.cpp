@@ -1788,7 +1788,7 @@ int frhot_ctx_stage_ms(frhot_ctx* c, float* ms5) {
 // DeepFace.extract_faces): YOLOv8n-pose layout with one class and five keypoints on a 640 x 640
 // letterboxed frame.  The graph is fixed, so it is written out here as a list of launches over
 // NHWC fp16 tensors; a concatenation is a tensor that two producers fill by channel slices.
-struct DetTensor { _Float16* p = nullptr; int h = 0, w = 0, c = 0; };
+struct DetTensor { _Float16* p = nullptr; int h = 0, w = 0, c = 0, div = 1; };   // h, w = canvas / div, set per call
 struct DetSlice { const DetTensor* t; int c0, c; };
 
 struct DetLayer { void* w = nullptr; float* b = nullptr; int k = 0, cin = 0, cout = 0; };   // cin / cout as stored (padded to 16)
@@ -1816,7 +1816,7 @@ int det_alloc(frhot_detector* d, void** p, size_t n) {
 }
 
 int det_tensor(frhot_detector* d, const char* name, int h, int w, int c) {
-    DetTensor t; t.h = h; t.w = w; t.c = c;
+    DetTensor t; t.h = h; t.w = w; t.c = c; t.div = 640 / h;        // allocated for the full 640 x 640 canvas
     const int rc = det_alloc(d, (void**)&t.p, (size_t)d->max_batch * h * w * c * 2);
     if (rc) return rc;
     d->t[name] = t;
@@ -1902,13 +1902,14 @@ struct DetRun {
     }
 };
 
-// The whole forward pass for B letterboxed frames in tensor "in" (enqueue only).
-int det_forward_enqueue(frhot_detector* d, int B) {
+// The whole forward pass for B letterboxed frames of ch x cw pixels in tensor "in" (enqueue only).
+int det_forward_enqueue(frhot_detector* d, int B, int ch, int cw) {
+    for (auto& kv : d->t) { kv.second.h = ch / kv.second.div; kv.second.w = cw / kv.second.div; }
     DetRun r{d, B, d->ctx->stream};
 #define FR_DET(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
     {
         const DetLayer& L0 = d->layers.at("m0");
-        HIP_TRY(launch_det_conv0(d->t.at("in").p, L0.w, L0.b, d->t.at("m0").p, B, d->ctx->stream));
+        HIP_TRY(launch_det_conv0(d->t.at("in").p, L0.w, L0.b, d->t.at("m0").p, B, ch, cw, d->ctx->stream));
     }
     FR_DET(r.conv("m1", r.all("m0"), r.all("m1"), 2, true));
     FR_DET(r.c2f("m2", r.all("m1"), "c2", "t2", r.all("m2"), 1, true));
@@ -2080,92 +2081,105 @@ int frhot_det_detect(frhot_detector* d, const uint8_t* const* images, const int3
     CropStaging st(c, sl);
     int rc = st.begin(images, hw, strides, B, 0);
     if (rc) return rc;
+    // Letterbox geometry as ultralytics' LetterBox computes it (float64, Python round = half to even).
+    // DeepFace predicts every frame on its own, which pads it only to the next multiple of 32 in each
+    // direction; frames whose canvases agree run as one batch here, the others one group after the other.
     std::vector<DetImageMeta> meta(B);
+    std::vector<std::pair<int, int>> canvas(B);
     for (int i = 0; i < B; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
         DetImageMeta& m = meta[i];
         m.offset = st.offsets[i]; m.h = h; m.w = w; m.stride = st.packed_strides[i];
-        // ratio and new size as ultralytics' LetterBox computes them (float64, Python round = half to even)
         const double r = std::min(640.0 / h, 640.0 / w);
         m.nw = (int)std::nearbyint(w * r); m.nh = (int)std::nearbyint(h * r);
         if (m.nw < 1 || m.nh < 1) return fail(FRHOT_EINVAL, "image %d: %dx%d letterboxes to an empty image", i, h, w);
-        const double dw = (640 - m.nw) / 2.0, dh = (640 - m.nh) / 2.0;
-        m.top = (int)std::nearbyint(dh - 0.1); m.left = (int)std::nearbyint(dw - 0.1);
+        const int pw = (640 - m.nw) % 32, ph = (640 - m.nh) % 32;
+        m.top = (int)std::nearbyint(ph / 2.0 - 0.1); m.left = (int)std::nearbyint(pw / 2.0 - 0.1);
         m.sy = (double)h / m.nh; m.sx = (double)w / m.nw;
+        canvas[i] = {m.nh + ph, m.nw + pw};
     }
-    // the context's lock is held to enqueue only; the wait for the answer leaves it to other callers
-    std::unique_lock<std::mutex> lk(c->mu);
-    hipStream_t s = c->stream;
-    HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
-    HIP_TRY(hipMemcpyAsync(d->meta_dev, meta.data(), sizeof(DetImageMeta) * B, hipMemcpyHostToDevice, s));
-    // (Replaying the letterbox and the ~110 launches of the forward pass from a captured graph was
-    // measured: 1.68 -> 1.62 ms for one frame.  The small maps' kernels are bound by their own serial
-    // K loops on a handful of blocks, not by launch gaps, so the launches stay plain.)
-    HIP_TRY(launch_det_letterbox(sl.dev, d->meta_dev, d->t.at("in").p, B, s));
-    rc = det_forward_enqueue(d, B);
-    if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    DetHead heads[3];
+    std::vector<char> done(B, 0);
     static const int strides_l[3] = {8, 16, 32};
-    for (int l = 0; l < 3; ++l) {
-        char n[16];
-        snprintf(n, sizeof n, "box%d", l); heads[l].box = d->t.at(n).p; heads[l].h = d->t.at(n).h; heads[l].w = d->t.at(n).w;
-        snprintf(n, sizeof n, "cls%d", l); heads[l].cls = d->t.at(n).p;
-        snprintf(n, sizeof n, "kpt%d", l); heads[l].kpt = d->t.at(n).p;
-        heads[l].stride = strides_l[l];
-    }
-    HIP_TRY(launch_det_decode(heads, conf, d->cand_dev, d->count_dev, frhot_detector::kCap, B, s));
-    HIP_TRY(hipMemcpyAsync(d->count_pin, d->count_dev, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(sl.done, s));
-    lk.unlock();
-    HIP_TRY(hipEventSynchronize(sl.done));
-    // the survivors of every image (their number is known only now), then suppression and the way back
-    // to the frame on the host: a handful of boxes
-    for (int i = 0; i < B; ++i)
-        if (d->count_pin[i] > frhot_detector::kCap)
-            return fail(FRHOT_ECAPACITY, "image %d: %d anchors above the confidence threshold (at most %d are kept)", i,
-                        d->count_pin[i], frhot_detector::kCap);
-    lk.lock();
-    for (int i = 0; i < B; ++i)
-        if (d->count_pin[i] > 0)
-            HIP_TRY(hipMemcpyAsync(d->cand_pin + (size_t)i * frhot_detector::kCap, d->cand_dev + (size_t)i * frhot_detector::kCap,
-                                   sizeof(DetCand) * d->count_pin[i], hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(sl.done, s));
-    lk.unlock();
-    HIP_TRY(hipEventSynchronize(sl.done));
-    for (int i = 0; i < B; ++i) {
-        const int n = d->count_pin[i];
-        const DetCand* cand = d->cand_pin + (size_t)i * frhot_detector::kCap;
-        std::vector<int> order(n);
-        for (int j = 0; j < n; ++j) order[j] = j;
-        std::sort(order.begin(), order.end(), [&](int a, int b) {
-            if (cand[a].v[4] != cand[b].v[4]) return cand[a].v[4] > cand[b].v[4];
-            return cand[a].anchor < cand[b].anchor;
-        });
-        std::vector<int> kept;
-        for (int j : order) {
-            bool ok = true;
-            for (int q : kept) if (det_iou(cand[j].v, cand[q].v) > iou) { ok = false; break; }
-            if (ok) { kept.push_back(j); if ((int)kept.size() == max_faces) break; }
+    for (int first = 0; first < B; ++first) {
+        if (done[first]) continue;
+        std::vector<int> idx;
+        std::vector<DetImageMeta> gm;
+        for (int i = first; i < B; ++i)
+            if (!done[i] && canvas[i] == canvas[first]) { idx.push_back(i); gm.push_back(meta[i]); done[i] = 1; }
+        const int n_g = (int)idx.size(), ch = canvas[first].first, cw = canvas[first].second;
+        // the context's lock is held to enqueue only; the waits for the answers leave it to other callers
+        std::unique_lock<std::mutex> lk(c->mu);
+        hipStream_t s = c->stream;
+        if (first == 0) HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
+        HIP_TRY(hipMemcpyAsync(d->meta_dev, gm.data(), sizeof(DetImageMeta) * n_g, hipMemcpyHostToDevice, s));
+        // (Replaying the letterbox and the ~110 launches of the forward pass from a captured graph was
+        // measured: 1.68 -> 1.62 ms for one frame.  The small maps' kernels are bound by their own serial
+        // K loops on a handful of blocks, not by launch gaps, so the launches stay plain.)
+        HIP_TRY(launch_det_letterbox(sl.dev, d->meta_dev, d->t.at("in").p, ch, cw, n_g, s));
+        rc = det_forward_enqueue(d, n_g, ch, cw);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        DetHead heads[3];
+        for (int l = 0; l < 3; ++l) {
+            char n[16];
+            snprintf(n, sizeof n, "box%d", l); heads[l].box = d->t.at(n).p; heads[l].h = d->t.at(n).h; heads[l].w = d->t.at(n).w;
+            snprintf(n, sizeof n, "cls%d", l); heads[l].cls = d->t.at(n).p;
+            snprintf(n, sizeof n, "kpt%d", l); heads[l].kpt = d->t.at(n).p;
+            heads[l].stride = strides_l[l];
         }
-        const DetImageMeta& m = meta[i];
-        const double r = std::min(640.0 / m.h, 640.0 / m.w);
-        auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
-        float* o = out + (size_t)i * max_faces * 20;
-        for (size_t q = 0; q < kept.size(); ++q) {
-            const float* v = cand[kept[q]].v;
-            float* w = o + q * 20;
-            w[0] = (float)clampd((v[0] - v[2] / 2 - m.left) / r, 0, m.w);
-            w[1] = (float)clampd((v[1] - v[3] / 2 - m.top) / r, 0, m.h);
-            w[2] = (float)clampd((v[0] + v[2] / 2 - m.left) / r, 0, m.w);
-            w[3] = (float)clampd((v[1] + v[3] / 2 - m.top) / r, 0, m.h);
-            w[4] = v[4];
-            for (int k = 0; k < 5; ++k) {
-                w[5 + 3 * k] = (float)clampd((v[5 + 3 * k] - m.left) / r, 0, m.w);
-                w[6 + 3 * k] = (float)clampd((v[6 + 3 * k] - m.top) / r, 0, m.h);
-                w[7 + 3 * k] = v[7 + 3 * k];
+        HIP_TRY(launch_det_decode(heads, conf, d->cand_dev, d->count_dev, frhot_detector::kCap, n_g, s));
+        HIP_TRY(hipMemcpyAsync(d->count_pin, d->count_dev, sizeof(int) * n_g, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(sl.done, s));
+        lk.unlock();
+        HIP_TRY(hipEventSynchronize(sl.done));
+        // the survivors of every frame (their number is known only now), then suppression and the way back
+        // to the frame on the host: a handful of boxes
+        for (int j = 0; j < n_g; ++j)
+            if (d->count_pin[j] > frhot_detector::kCap)
+                return fail(FRHOT_ECAPACITY, "image %d: %d anchors above the confidence threshold (at most %d are kept)",
+                            idx[j], d->count_pin[j], frhot_detector::kCap);
+        lk.lock();
+        for (int j = 0; j < n_g; ++j)
+            if (d->count_pin[j] > 0)
+                HIP_TRY(hipMemcpyAsync(d->cand_pin + (size_t)j * frhot_detector::kCap, d->cand_dev + (size_t)j * frhot_detector::kCap,
+                                       sizeof(DetCand) * d->count_pin[j], hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(sl.done, s));
+        lk.unlock();
+        HIP_TRY(hipEventSynchronize(sl.done));
+        for (int j = 0; j < n_g; ++j) {
+            const int i = idx[j], n = d->count_pin[j];
+            const DetCand* cand = d->cand_pin + (size_t)j * frhot_detector::kCap;
+            std::vector<int> order(n);
+            for (int q = 0; q < n; ++q) order[q] = q;
+            std::sort(order.begin(), order.end(), [&](int a, int b) {
+                if (cand[a].v[4] != cand[b].v[4]) return cand[a].v[4] > cand[b].v[4];
+                return cand[a].anchor < cand[b].anchor;
+            });
+            std::vector<int> kept;
+            for (int q : order) {
+                bool ok = true;
+                for (int p : kept) if (det_iou(cand[q].v, cand[p].v) > iou) { ok = false; break; }
+                if (ok) { kept.push_back(q); if ((int)kept.size() == max_faces) break; }
             }
+            const DetImageMeta& m = meta[i];
+            const double r = std::min(640.0 / m.h, 640.0 / m.w);
+            auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+            float* o = out + (size_t)i * max_faces * 20;
+            for (size_t q = 0; q < kept.size(); ++q) {
+                const float* v = cand[kept[q]].v;
+                float* w = o + q * 20;
+                w[0] = (float)clampd((v[0] - v[2] / 2 - m.left) / r, 0, m.w);
+                w[1] = (float)clampd((v[1] - v[3] / 2 - m.top) / r, 0, m.h);
+                w[2] = (float)clampd((v[0] + v[2] / 2 - m.left) / r, 0, m.w);
+                w[3] = (float)clampd((v[1] + v[3] / 2 - m.top) / r, 0, m.h);
+                w[4] = v[4];
+                for (int k = 0; k < 5; ++k) {
+                    w[5 + 3 * k] = (float)clampd((v[5 + 3 * k] - m.left) / r, 0, m.w);
+                    w[6 + 3 * k] = (float)clampd((v[6 + 3 * k] - m.top) / r, 0, m.h);
+                    w[7 + 3 * k] = v[7 + 3 * k];
+                }
+            }
+            counts[i] = (int32_t)kept.size();
         }
-        counts[i] = (int32_t)kept.size();
     }
     return FRHOT_OK;
     });

@@ -58,18 +58,18 @@ struct DetConv {
 };
 struct DetImageMeta {
     int64_t offset; int h, w, stride;                // the frame inside the staged bytes
-    int nh, nw, top, left;                           // resized size and its place on the 640 x 640 canvas
+    int nh, nw, top, left;                           // resized size and its place on the canvas
     double sy, sx;                                   // source pixels per resized pixel
 };
 struct DetHead { const _Float16 *box, *cls, *kpt; int h, w, stride; };   // [B,h,w,64], [B,h,w,16] (channel 0), [B,h,w,16] (15)
 struct DetCand { float v[20]; int anchor; };         // cx, cy, w, h (canvas), score, 5 x (x, y, visibility)
 hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s);
-hipError_t launch_det_conv0(const void* x, const void* w64, const float* bias, void* y, int B, hipStream_t s);
+hipError_t launch_det_conv0(const void* x, const void* w64, const float* bias, void* y, int B, int H, int W, hipStream_t s);
 hipError_t launch_det_maxpool5(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
                                hipStream_t s);
 hipError_t launch_det_upsample2(const void* x, int xc, int xc0, void* y, int yc, int yc0, int C, int H, int W, int B,
                                 hipStream_t s);
-hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out4, int B, hipStream_t s);   // [B,640,640,4]
+hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out4, int ch, int cw, int B, hipStream_t s);   // [B,ch,cw,4]
 hipError_t launch_det_decode(const DetHead* heads3, float conf, DetCand* cand, int* counts, int cap, int B, hipStream_t s);
 // Split-K GEMM partial[z][m][n] = sum_{k in slice z} x[m][k] * w[n][k]; M rows of x,
 // N rows of w, K multiple of 64*splitk, N multiple of 128.

@@ -3535,17 +3535,17 @@ __global__ __launch_bounds__(256) void det_upsample2_kernel(const half_t* __rest
         *(const half8*)(x + ((b * H + (py >> 1)) * W + (px >> 1)) * xc + xc0 + ch);
 }
 
-// Letterbox of a BGR frame onto the 640 x 640 canvas: bilinear resize with half-pixel centres
+// Letterbox of a BGR frame onto the ch x cw canvas (multiples of 32, at most 640): bilinear resize with half-pixel centres
 // (float32, rounded to whole levels as a uint8 resize returns them), 114 outside, RGB order,
 // / 255, written as 4 channels (RGB and a zero), 8 bytes per pixel.
 __global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __restrict__ imgs,
                                                             const DetImageMeta* __restrict__ meta,
-                                                            half_t* __restrict__ out) {
+                                                            half_t* __restrict__ out, int ch, int cw) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;       // canvas pixel
-    if (p >= 640 * 640) return;
+    if (p >= ch * cw) return;
     const DetImageMeta m = meta[b];
-    const int cy = p / 640, cx = p - cy * 640;
+    const int cy = p / cw, cx = p - cy * cw;
     float rgb[3] = {114.f, 114.f, 114.f};
     const int y = cy - m.top, x = cx - m.left;
     if (y >= 0 && y < m.nh && x >= 0 && x < m.nw) {
@@ -3574,7 +3574,7 @@ __global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __res
     }
     half4v o;
     o[0] = (half_t)(rgb[0] / 255.0f); o[1] = (half_t)(rgb[1] / 255.0f); o[2] = (half_t)(rgb[2] / 255.0f); o[3] = (half_t)0.f;
-    *(half4v*)(out + ((long)b * 640 * 640 + p) * 4) = o;
+    *(half4v*)(out + ((long)b * ch * cw + p) * 4) = o;
 }
 
 // The first convolution (3 -> 16 channels, 3 x 3, stride 2) on the 4-channel canvas: K = 9 taps x 4
@@ -3583,8 +3583,9 @@ __global__ __launch_bounds__(256) void det_letterbox_kernel(const uint8_t* __res
 // network).  As 16 zero-padded input channels through the generic kernel it was the most expensive
 // launch of the network (0.18 ms per 32 frames) and the canvas four times as large.
 __global__ __launch_bounds__(256) void det_conv0_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w64,
-                                                        const float* __restrict__ bias, half_t* __restrict__ y, int M) {
-    constexpr int H = 640, W = 640, Ho = 320, Wo = 320;
+                                                        const float* __restrict__ bias, half_t* __restrict__ y, int M,
+                                                        int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const half8 a0 = *(const half8*)(w64 + l15 * 64 + 8 * g);
     const half8 a1 = *(const half8*)(w64 + l15 * 64 + 32 + 8 * g);
@@ -3602,7 +3603,7 @@ __global__ __launch_bounds__(256) void det_conv0_kernel(const half_t* __restrict
         const half_t* img = x + (long)b * H * W * 4;
         auto tap = [&](int t) __attribute__((always_inline)) -> half4v {
             const int iy = 2 * oy + t / 3 - 1, ix = 2 * ox + t % 3 - 1;
-            const bool ok = iy >= 0 && ix >= 0;                 // (the far edges stay inside: 2 * 319 + 1 = 639)
+            const bool ok = iy >= 0 && ix >= 0;                 // (the far edges stay inside: H and W are even)
             const half4v v = *(const half4v*)(img + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 4);
             return ok ? v : z4;
         };
@@ -3987,12 +3988,12 @@ hipError_t launch_det_conv(const DetConv& d, int B, hipStream_t s) {
     return hipSuccess;
 }
 
-// x [B,640,640,4] -> y [B,320,320,16]; w64 [16][64] with k = tap * 4 + channel (zero elsewhere)
-hipError_t launch_det_conv0(const void* x, const void* w64, const float* bias, void* y, int B, hipStream_t s) {
-    if (B <= 0 || !x || !w64 || !bias || !y) return hipErrorInvalidValue;
-    const long M = (long)B * 320 * 320;
+// x [B,H,W,4] -> y [B,H/2,W/2,16]; w64 [16][64] with k = tap * 4 + channel (zero elsewhere)
+hipError_t launch_det_conv0(const void* x, const void* w64, const float* bias, void* y, int B, int H, int W, hipStream_t s) {
+    if (B <= 0 || !x || !w64 || !bias || !y || H <= 0 || W <= 0 || (H | W) % 2) return hipErrorInvalidValue;
+    const long M = (long)B * (H / 2) * (W / 2);
     hipLaunchKernelGGL(det_conv0_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const half_t*)x,
-                       (const half_t*)w64, bias, (half_t*)y, (int)M);
+                       (const half_t*)w64, bias, (half_t*)y, (int)M, H, W);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
@@ -4017,9 +4018,10 @@ hipError_t launch_det_upsample2(const void* x, int xc, int xc0, void* y, int yc,
     return hipSuccess;
 }
 
-hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out16, int B, hipStream_t s) {
-    if (B <= 0 || !imgs || !meta || !out16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(det_letterbox_kernel, dim3(1600, B), dim3(256), 0, s, imgs, meta, (half_t*)out16);
+hipError_t launch_det_letterbox(const uint8_t* imgs, const DetImageMeta* meta, void* out4, int ch, int cw, int B, hipStream_t s) {
+    if (B <= 0 || !imgs || !meta || !out4 || ch <= 0 || cw <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(det_letterbox_kernel, dim3((unsigned)((ch * cw + 255) / 256), B), dim3(256), 0, s, imgs, meta,
+                       (half_t*)out4, ch, cw);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }

@@ -70,7 +70,21 @@ def _macs():
     return total
 
 
-MACS_PER_FRAME = _macs()
+MACS_PER_FRAME = _macs()       # on the full 640 x 640 canvas
+
+
+def canvas_of(h: int, w: int):
+    """(rows, columns) of the canvas a frame of h x w pixels is detected on: the frame scaled to fit
+    640 x 640, padded to the next multiple of 32 in each direction (ultralytics' LetterBox for a frame
+    predicted on its own, which is what DeepFace does)."""
+    r = min(IMG / h, IMG / w)
+    nw, nh = int(round(w * r)), int(round(h * r))
+    return nh + (IMG - nh) % 32, nw + (IMG - nw) % 32
+
+
+def macs_for(h: int, w: int) -> float:
+    ch, cw = canvas_of(h, w)
+    return MACS_PER_FRAME * (ch * cw) / float(IMG * IMG)
 
 
 def synthetic_weights(seed: int = 0xFACE, cls_bias: float = -6.0) -> dict:

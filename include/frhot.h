@@ -287,8 +287,10 @@ int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, cons
 /*
  * The face detector of the reference's DeepFace.extract_faces(detector_backend="yolov8") calls
  * (app/src/utils/legacy.py:60-65 on the whole frame, :80-86 in detect_face): a YOLOv8n-pose network
- * with one class and five keypoints (the yolov8n-face.pt file of app/Dockerfile:82-84) on a
- * 640 x 640 letterboxed frame, then confidence selection and greedy IoU suppression.
+ * with one class and five keypoints (the yolov8n-face.pt file of app/Dockerfile:82-84) on the
+ * letterboxed frame (scaled to fit 640 x 640, padded to the next multiple of 32 in each direction,
+ * as ultralytics does for a frame predicted on its own), then confidence selection and greedy IoU
+ * suppression.  Frames of one call whose canvases agree run as one batch.
  * frhot_det_create: blob = the library's weight container ("FRHOTW01") holding, for every
  *   convolution of the network, "<name>.w" fp16 [cout][k][k][cin] with the batch norm folded in and
  *   "<name>.b" fp32 (names: frhot/detector.py, CONVS).  max_batch <= 64 frames per call; the
@@ -301,7 +303,8 @@ int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, cons
  *   overlap a better one by more than this are dropped (0.7).  Waits for the result.
  *   FRHOT_ECAPACITY when more than 2048 anchors of one frame pass `conf` (not a face detector's
  *   weights, or a threshold near zero).
- * frhot_det_debug_read: one named activation tensor of the last call ([B,h,w,c] fp16), for tests.
+ * frhot_det_debug_read: one named activation tensor of the last call's last group of frames
+ *   ([B,h,w,c] fp16, h and w following that group's canvas), for tests.
  * Anti-spoofing (the `is_real` field DeepFace adds with a second network) is not part of this.
  */
 typedef struct frhot_detector frhot_detector;

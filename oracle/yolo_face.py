@@ -25,10 +25,12 @@ plus the input when `shortcut`) each fed by the previous half, cv2 1x1 (2+n)c ->
 SPPF: cv1 1x1 c->c/2, three chained 5x5/1 max pools, cv2 1x1 over the four maps.
 
 FLAGS (re-verify against ultralytics + deepface where they exist):
-  D1 letterbox: fixed 640x640 canvas, ratio min(640/h, 640/w) (enlarging allowed), new size
-     (round(w r), round(h r)), bilinear resize with half-pixel centres in float (OpenCV's uint8
-     fixed-point path differs by at most one level), padding 114 split round(d -/+ 0.1);
-     ultralytics pads a single image to the next multiple of 32 instead of the full square;
+  D1 letterbox: ratio min(640/h, 640/w) (enlarging allowed), new size (round(w r), round(h r)),
+     bilinear resize with half-pixel centres in float (OpenCV's uint8 fixed-point path differs by
+     at most one level), padding 114 split round(d -/+ 0.1).  A frame predicted alone (what DeepFace
+     does) is padded only to the next multiple of 32 in each direction ("auto" of ultralytics'
+     LetterBox, used when all images of a call share one shape); `auto=False` gives the full
+     640 x 640 square ultralytics uses for a call with images of different shapes;
   D2 BGR -> RGB, /255, no mean;
   D3 decode: box distances = expectation over softmax of 16 bins; xywh from anchor centre
      (cell + 0.5) -/+ distances, times the stride; keypoint x = (2 v + cell) * stride with cell
@@ -99,13 +101,17 @@ SHORTCUT = {"m2": True, "m4": True, "m6": True, "m8": True, "m12": False, "m15":
 C2F_N = {"m2": 1, "m4": 2, "m6": 2, "m8": 1, "m12": 1, "m15": 1, "m18": 1, "m21": 1}
 
 
-def letterbox(img_bgr: np.ndarray):
-    """uint8 [h, w, 3] BGR -> (float32 [640, 640, 3] RGB in [0, 1], ratio, (pad_left, pad_top)).  FLAGS D1, D2."""
+def letterbox(img_bgr: np.ndarray, auto: bool = True):
+    """uint8 [h, w, 3] BGR -> (float32 [H, W, 3] RGB in [0, 1], ratio, (pad_left, pad_top)); H, W are
+    multiples of 32, at most 640.  FLAGS D1, D2."""
     h, w = img_bgr.shape[:2]
     r = min(IMG / h, IMG / w)
     nw, nh = int(round(w * r)), int(round(h * r))
-    dw, dh = (IMG - nw) / 2, (IMG - nh) / 2
-    top, left = int(round(dh - 0.1)), int(round(dw - 0.1))
+    dw, dh = IMG - nw, IMG - nh
+    if auto:
+        dw, dh = dw % 32, dh % 32
+    top, left = int(round(dh / 2 - 0.1)), int(round(dw / 2 - 0.1))
+    bottom, right = int(round(dh / 2 + 0.1)), int(round(dw / 2 + 0.1))
     src = img_bgr.astype(np.float32)
     if (nh, nw) != (h, w):
         sy, sx = h / nh, w / nw
@@ -124,7 +130,7 @@ def letterbox(img_bgr: np.ndarray):
         out = np.floor(out + 0.5)                     # back to whole levels, as a uint8 resize returns
     else:
         out = src
-    canvas = np.full((IMG, IMG, 3), 114.0, np.float32)
+    canvas = np.full((nh + top + bottom, nw + left + right, 3), 114.0, np.float32)
     canvas[top:top + nh, left:left + nw] = out
     return canvas[:, :, ::-1] / np.float32(255.0), r, (left, top)
 
@@ -252,10 +258,10 @@ def nms(boxes, scores, iou: float = 0.7, max_det: int = 300):
     return kept
 
 
-def regions(img_bgr: np.ndarray, weights: dict, conf: float = 0.25):
+def regions(img_bgr: np.ndarray, weights: dict, conf: float = 0.25, auto: bool = True):
     """DeepFace-style regions of one image: [{"x","y","w","h","left_eye","right_eye","confidence"}] in
     descending confidence.  FLAGS D5, D6."""
-    x, r, (left, top) = letterbox(img_bgr)
+    x, r, (left, top) = letterbox(img_bgr, auto)
     boxes, scores, kpts = decode(forward(x[None], weights), conf)[0]
     H, W = img_bgr.shape[:2]
     out = []

@@ -24,7 +24,7 @@ def main():
     for _ in range(iters):
         det.detect(frames)
     dt = (time.perf_counter() - t) / iters
-    fl = 2.0 * D.MACS_PER_FRAME * batch
+    fl = 2.0 * D.macs_for(480, 640) * batch
     print(f"detect: batch {batch}: {dt * 1e3:.3f} ms per call, {batch / dt:.0f} frames/s, {fl / dt / 1e12:.1f} TFLOP/s "
           f"({fl / dt / 2.5e15:.3f} of 2.5 PFLOP/s)")
     det.close()

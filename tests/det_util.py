@@ -9,7 +9,7 @@ def calibrated_weights(seed: int = 3, cls_bias: float = -6.0):
     from oracle import yolo_face as O
     w = D.synthetic_weights(seed, cls_bias=cls_bias)
     imgs = S.crops(seed=seed + 100, n=2, lo=400, hi=640)
-    x = np.stack([O.letterbox(im)[0] for im in imgs])
+    x = np.stack([O.letterbox(im, auto=False)[0] for im in imgs])
     with np.errstate(over="ignore"):
         O.forward(x, w, calibrate=True)
     wq = {k: (v.astype(np.float16).astype(np.float32) if k.endswith(".w") else v) for k, v in w.items()}

@@ -66,16 +66,26 @@ def test_converter_folds_batch_norm():
 def test_oracle_letterbox_geometry():
     from oracle import yolo_face as O
     img = np.full((480, 640, 3), (10, 20, 30), np.uint8)          # BGR
-    x, r, (left, top) = O.letterbox(img)
-    assert r == 1.0 and (left, top) == (0, 80)
+    x, r, (left, top) = O.letterbox(img, auto=False)              # the full square
+    assert x.shape == (640, 640, 3) and r == 1.0 and (left, top) == (0, 80)
     assert np.allclose(x[79, 0], 114 / 255) and np.allclose(x[80, 0], [30 / 255, 20 / 255, 10 / 255])      # RGB
     assert np.allclose(x[559, 639], [30 / 255, 20 / 255, 10 / 255]) and np.allclose(x[560, 0], 114 / 255)
+    x, r, (left, top) = O.letterbox(img)                          # a frame on its own: the minimal rectangle
+    assert x.shape == (480, 640, 3) and (left, top) == (0, 0) and np.allclose(x[0, 0], [30 / 255, 20 / 255, 10 / 255])
+    x, r, (left, top) = O.letterbox(np.zeros((469, 648, 3), np.uint8))
+    assert x.shape == (480, 640, 3) and (left, top) == (0, 8) and x[7, 0, 0] == np.float32(114 / 255) and x[8, 0, 0] == 0
+    assert x[470, 0, 0] == 0 and x[471, 0, 0] == np.float32(114 / 255)          # 463 rows, 8 above and 9 below
     tall = np.zeros((1280, 320, 3), np.uint8)
     x, r, (left, top) = O.letterbox(tall)
+    assert x.shape == (640, 160, 3) and r == 0.5 and (left, top) == (0, 0)
+    x, r, (left, top) = O.letterbox(tall, auto=False)
     assert r == 0.5 and (left, top) == (240, 0) and x[0, 239, 0] == np.float32(114 / 255) and x[0, 240, 0] == 0
     small = np.zeros((100, 50, 3), np.uint8)                        # enlarged
     x, r, (left, top) = O.letterbox(small)
-    assert r == 6.4 and (left, top) == (160, 0)
+    assert x.shape == (640, 320, 3) and r == 6.4 and (left, top) == (0, 0)
+    for h, w in ((333, 517), (719, 1279), (64, 640), (641, 640), (1, 1), (5, 4000)):
+        x, _r, _p = O.letterbox(np.zeros((h, w, 3), np.uint8))
+        assert x.shape[0] % 32 == 0 and x.shape[1] % 32 == 0 and 32 <= x.shape[0] <= 640 and 32 <= x.shape[1] <= 640
 
 
 def test_oracle_decode_hand_case():

@@ -22,43 +22,43 @@ def test_letterbox_bit_exact(det):
     from oracle import yolo_face as O
     d, _wq = det
     rng = np.random.default_rng(1)
-    shapes = [(480, 640), (640, 640), (1280, 320), (100, 50), (333, 517), (719, 1279), (641, 640), (64, 640)]
+    shapes = [(480, 640), (640, 640), (1280, 320), (100, 50), (333, 517), (719, 1279), (641, 640), (64, 640), (469, 648)]
     imgs = [(rng.random((h, w, 3)) * 255).astype(np.uint8) for h, w in shapes]
     big = (rng.random((500, 700, 3)) * 255).astype(np.uint8)
     imgs.append(big[20:420, 100:650])                     # a row-strided view
-    for i in range(0, len(imgs), 4):
-        part = imgs[i:i + 4]
-        d.detect(part)
-        got = d.debug_read("in", len(part), 640, 640, 4)
-        for j, im in enumerate(part):
-            want = O.letterbox(im)[0].astype(np.float16)
-            assert np.array_equal(got[j, :, :, :3], want), f"image {i + j} {im.shape}"
-            assert not got[j, :, :, 3:].any()
+    for i, im in enumerate(imgs):
+        want = O.letterbox(im)[0].astype(np.float16)      # the minimal rectangle of a frame on its own
+        d.detect([im])
+        got = d.debug_read("in", 1, want.shape[0], want.shape[1], 4)
+        assert np.array_equal(got[0, :, :, :3], want), f"image {i} {im.shape}"
+        assert not got[0, :, :, 3].any()
 
 
 def test_blocks_match_oracle(det):
     from oracle import yolo_face as O
     d, wq = det
-    imgs = frames(seed=9, n=2)
-    d.detect(imgs)
-    x = np.stack([O.letterbox(im)[0] for im in imgs])
-    taps = {}
-    outs = O.forward(x, wq, taps)
-    where = {"m0": ("m0", 320, 16, 0), "m1": ("m1", 160, 32, 0), "m2": ("m2", 160, 32, 0), "m3": ("m3", 80, 64, 0),
-             "m4": ("cat14", 80, 192, 128), "m5": ("m5", 40, 128, 0), "m6": ("cat11", 40, 384, 256), "m7": ("m7", 20, 256, 0),
-             "m8": ("m8", 20, 256, 0), "m9": ("cat20", 20, 384, 128), "m12": ("cat17", 40, 192, 64), "m15": ("o3", 80, 64, 0),
-             "m18": ("o4", 40, 128, 0), "m21": ("o5", 20, 256, 0)}
-    for name, (tensor, hw, c, c0) in where.items():
-        ref = taps[name]
-        got = d.debug_read(tensor, 2, hw, hw, c)[..., c0:c0 + ref.shape[-1]].astype(np.float32)
-        err, scale = np.abs(got - ref).max(), np.abs(ref).max()
-        assert err <= 1e-2 * scale, f"{name}: max err {err} vs scale {scale}"
-    for l, (box, cls, kpt) in enumerate(outs):
-        hw = box.shape[1]
-        for nm, ref, c in (("box", box, 64), ("cls", cls, 16), ("kpt", kpt, 16)):
-            got = d.debug_read(f"{nm}{l}", 2, hw, hw, c)[..., :ref.shape[-1]].astype(np.float32)
+    where = {"m0": ("m0", 2, 16, 0), "m1": ("m1", 4, 32, 0), "m2": ("m2", 4, 32, 0), "m3": ("m3", 8, 64, 0),
+             "m4": ("cat14", 8, 192, 128), "m5": ("m5", 16, 128, 0), "m6": ("cat11", 16, 384, 256), "m7": ("m7", 32, 256, 0),
+             "m8": ("m8", 32, 256, 0), "m9": ("cat20", 32, 384, 128), "m12": ("cat17", 16, 192, 64), "m15": ("o3", 8, 64, 0),
+             "m18": ("o4", 16, 128, 0), "m21": ("o5", 32, 256, 0)}
+    same = frames(seed=9, n=1, lo=500, hi=640)[0]
+    for imgs in ([same, same[::-1].copy()], [frames(seed=10, n=1, lo=240, hi=420)[0]]):       # a batch of two, a small frame
+        d.detect(imgs)
+        x = np.stack([O.letterbox(im)[0] for im in imgs])
+        H, W = x.shape[1:3]
+        taps = {}
+        outs = O.forward(x, wq, taps)
+        for name, (tensor, div, c, c0) in where.items():
+            ref = taps[name]
+            got = d.debug_read(tensor, len(imgs), H // div, W // div, c)[..., c0:c0 + ref.shape[-1]].astype(np.float32)
             err, scale = np.abs(got - ref).max(), np.abs(ref).max()
-            assert err <= 1.5e-2 * scale, f"{nm}{l}: max err {err} vs scale {scale}"
+            assert err <= 1e-2 * scale, f"{name}: max err {err} vs scale {scale}"
+        for l, (box, cls, kpt) in enumerate(outs):
+            h, w = box.shape[1:3]
+            for nm, ref, c in (("box", box, 64), ("cls", cls, 16), ("kpt", kpt, 16)):
+                got = d.debug_read(f"{nm}{l}", len(imgs), h, w, c)[..., :ref.shape[-1]].astype(np.float32)
+                err, scale = np.abs(got - ref).max(), np.abs(ref).max()
+                assert err <= 1.5e-2 * scale, f"{nm}{l}: max err {err} vs scale {scale}"
 
 
 def _match(got, ref_boxes, ref_scores, ref_kpts, tol_px, tol_s):
