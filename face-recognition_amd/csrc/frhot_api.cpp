@@ -1803,7 +1803,7 @@ struct frhot_detector {
     _Float16* zeros = nullptr;                      // 4 KiB: the input of a tap outside the image
     DetCand* cand_dev = nullptr; int* count_dev = nullptr;
     DetCand* cand_pin = nullptr; int* count_pin = nullptr;
-    static constexpr int kCap = 2048;               // candidates kept per image before suppression
+    static constexpr int kCap = 8400;               // candidates per image before suppression: every anchor of a full canvas
     std::mutex dmu;                                 // one detect call at a time (the activation tensors are the detector's)
 };
 

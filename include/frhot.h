@@ -301,8 +301,6 @@ int frhot_search_sharded_dev(frhot_gallery* g, const void* q_local_f16_dev, cons
  *   (x, y, visibility): right eye, left eye, nose, right and left mouth corner in image order.
  *   conf: class score a face must exceed (the reference's backend uses 0.25); iou: boxes that
  *   overlap a better one by more than this are dropped (0.7).  Waits for the result.
- *   FRHOT_ECAPACITY when more than 2048 anchors of one frame pass `conf` (not a face detector's
- *   weights, or a threshold near zero).
  * frhot_det_debug_read: one named activation tensor of the last call's last group of frames
  *   ([B,h,w,c] fp16, h and w following that group's canvas), for tests.
  * Anti-spoofing (the `is_real` field DeepFace adds with a second network) is not part of this.
