@@ -28,13 +28,14 @@ def _crop_args(images):
         if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
             raise ValueError("crops must be uint8 arrays of shape [h, w, 3] (BGR)")
         st = im.strides
-        if st[2] != 1 or st[1] != 3 or st[0] < 3 * im.shape[1]:
+        # (the row stride of a one-row image means nothing: numpy keeps whatever the view had)
+        if st[2] != 1 or st[1] != 3 or (im.shape[0] > 1 and st[0] < 3 * im.shape[1]):
             im = np.ascontiguousarray(im)
         arrs.append(im)
     n = len(arrs)
     addr = np.fromiter((a.__array_interface__["data"][0] for a in arrs), dtype=np.uint64, count=n)
     hw = np.array([a.shape[:2] for a in arrs], dtype=np.int32).reshape(n, 2)
-    strides = np.fromiter((a.strides[0] for a in arrs), dtype=np.int32, count=n)
+    strides = np.fromiter((a.strides[0] if a.shape[0] > 1 else 3 * a.shape[1] for a in arrs), dtype=np.int32, count=n)
     ptrs = addr.ctypes.data_as(C.POINTER(C.POINTER(C.c_uint8)))
     return (arrs, addr), ptrs, hw, strides
 

@@ -780,3 +780,15 @@ def test_row_allocator_keeps_a_keys_rows_together():
     assert len(set(got)) == free and not set(got) & set(a + b + c)
     with pytest.raises(MemoryError):
         al.alloc(13)
+
+
+def test_crop_args_one_row_view_gets_a_usable_stride():
+    """A one-row image keeps whatever row stride its view had (numpy ignores the stride of a
+    length-one axis, also in ascontiguousarray): the marshalled stride is the row length."""
+    from frhot.engine import _crop_args
+    one = np.ascontiguousarray(np.zeros((1, 7, 3), np.uint8)[::-1])
+    assert one.strides[0] < 0
+    rev = np.zeros((5, 4, 3), np.uint8)[::-1]
+    wide = np.zeros((6, 10, 3), np.uint8)[:, 2:7]
+    _keep, _ptrs, hw, strides = _crop_args([one, rev, wide])
+    assert hw.tolist() == [[1, 7], [5, 4], [6, 5]] and strides.tolist() == [21, 12, 30]
