@@ -2189,6 +2189,7 @@ int frhot_det_debug_read(frhot_detector* d, const char* name, int B, void* host_
     return guarded([&]() -> int {
     if (!d || !name || !host_out) return fail(FRHOT_EINVAL, "null argument");
     if (B <= 0 || B > d->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, d->max_batch);
+    std::lock_guard<std::mutex> dlk(d->dmu);        // (a detect call in flight changes the tensors' sizes)
     const auto it = d->t.find(name);
     if (it == d->t.end()) return fail(FRHOT_EINVAL, "the detector has no tensor '%s'", name);
     const size_t need = (size_t)B * it->second.h * it->second.w * it->second.c * 2;
