@@ -65,16 +65,22 @@ def build_router(face_service, api_key: str = DEFAULT_API_KEY) -> APIRouter:
 
 
 def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max_delay_s: float = 0.002,
-               fused: bool = True, quality_gates: bool = False) -> FastAPI:
+               fused: bool = True, quality_gates: bool = False, detector=None, anti_spoof=None,
+               assume_real: bool = False) -> FastAPI:
     """A FastAPI app serving the two routes from one GPU context with a loaded model.
     `fused`: requests in flight together share ONE frhot_recognise call each round (crops in,
     voted answers out); False serves through the two seams get_embedding / search_point with one
     micro-batcher each, as a maintainer who patches only those seams would run it.
     `quality_gates`: employees' recognition requests pass the reference's check-in gates
     (face_service.py:73-219): blur on this context, the others over the models registered with
-    frhot.quality.install_models."""
+    frhot.quality.install_models.
+    `detector`: a frhot.detector.Detector on this context.  It takes the place of DeepFace's yolov8
+    backend behind detect_face and the spoof pass (legacy.py:60-65,80-86): frames of requests in
+    flight share device calls through a DetectBatcher.  DeepFace's anti-spoofing network is not part
+    of this package: `anti_spoof(face crop) -> bool` supplies its verdict, or `assume_real=True`
+    accepts every face.  Needs `quality_gates` (the service detects only with the gates on)."""
     from . import legacy, quality
-    from .batcher import EmbedBatcher, RecogniseBatcher, SearchBatcher
+    from .batcher import DetectBatcher, EmbedBatcher, RecogniseBatcher, SearchBatcher
     from .database_client import DatabaseClient
     from .face_service import FaceService
     from .gallery_service import GalleryService
@@ -83,6 +89,17 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
     legacy.install_engine(batcher)
     if quality_gates:
         quality.install_engine(ctx)
+    det_batcher = None
+    if detector is not None:
+        if not quality_gates:
+            raise ValueError("a detector is used by the quality gates only: pass quality_gates=True")
+        if anti_spoof is None and not assume_real:
+            raise ValueError("no anti-spoofing model: pass anti_spoof=callable, or assume_real=True to accept every face")
+        det_batcher = DetectBatcher(detector, max_delay_s=max_delay_s)
+        installed = quality.installed_models()
+        quality.install_models(face_mesh=installed["face_mesh"], face_detection=installed["face_detection"],
+                               extract_faces=lambda image: det_batcher.extract_faces(
+                                   image, expand_percentage=quality.FACE_EXT, anti_spoof=anti_spoof, assume_real=assume_real))
     service = GalleryService(ctx, capacity=capacity)
     search_batcher = SearchBatcher(service, max_delay_s=max_delay_s)
     recogniser = RecogniseBatcher(service, ctx.max_batch, max_delay_s=max_delay_s) if fused else None
@@ -95,8 +112,12 @@ def create_app(ctx, capacity: int = 1 << 16, api_key: str = DEFAULT_API_KEY, max
     app.state.gallery_service = service
     app.state.face_service = face_service
     app.state.recogniser = recogniser
+    app.state.det_batcher = det_batcher
 
     def close():
+        if det_batcher is not None:
+            det_batcher.close()
+            quality.install_models(face_mesh=installed["face_mesh"], face_detection=installed["face_detection"])
         batcher.close()
         search_batcher.close()
         if recogniser is not None:

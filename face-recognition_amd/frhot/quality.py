@@ -23,6 +23,7 @@ EYE_AR_THRESH = 0.2
 BLUR_THRESHOLD = 100
 LEFT_RIGHT_FACE_THRESHOLD = 2.5
 CONF_THRESHOLD = 0.8
+FACE_EXT = 10                      # per cent the detector's boxes are enlarged by (settings.py:39, legacy.py:84)
 LEFT_EYE_LANDMARKS = (33, 160, 158, 133, 153, 144)      # settings.py:43-44
 RIGHT_EYE_LANDMARKS = (362, 385, 387, 263, 373, 380)
 
@@ -46,6 +47,11 @@ def install_models(face_mesh=None, face_detection=None, extract_faces=None) -> N
     expand_percentage=10, anti_spoofing=True)."""
     global _face_mesh, _face_detection, _extract_faces
     _face_mesh, _face_detection, _extract_faces = face_mesh, face_detection, extract_faces
+
+
+def installed_models() -> dict:
+    """The registered callables themselves (None where nothing is registered)."""
+    return {"face_mesh": _face_mesh, "face_detection": _face_detection, "extract_faces": _extract_faces}
 
 
 def models_installed() -> dict:

@@ -229,3 +229,71 @@ def test_detect_batcher_on_the_gpu(det):
             assert np.array_equal(g, w)
     finally:
         b.close()
+
+
+def test_create_refuses_a_blob_of_another_network(gpu_ctx, weights_f32):
+    from frhot import FrhotError, detector as D
+    from frhot.weights import pack_blob
+    with pytest.raises(FrhotError) as e:
+        D.Detector(gpu_ctx, pack_blob(weights_f32), max_batch=1)
+    assert e.value.code == -1 and "m0.w" in str(e.value)
+    with pytest.raises(FrhotError):
+        D.Detector(gpu_ctx, D.pack_blob(D.synthetic_weights(1)), max_batch=65)
+
+
+def test_app_serves_frames_through_the_gpu_detector(det, gpu_ctx):
+    """create_app with the detector registered: an employee's check-in request carries a whole frame,
+    the service detects on the GPU (frames of requests in flight share device calls), crops the nearest
+    face, and recognises it: enrolling a frame makes the same frame answer with the enrolled id."""
+    import asyncio
+    import base64
+    import io
+
+    import httpx
+    from PIL import Image
+
+    from frhot import quality
+    from frhot.api import create_app
+    d, _wq = det
+    with pytest.raises(ValueError):
+        create_app(gpu_ctx, detector=d, quality_gates=True)                 # no anti-spoofing policy
+    with pytest.raises(ValueError):
+        create_app(gpu_ctx, detector=d, assume_real=True)                   # the gates are off
+    app = create_app(gpu_ctx, capacity=256, api_key="k", max_delay_s=0.01, quality_gates=True, detector=d, assume_real=True)
+
+    def b64(img):
+        buf = io.BytesIO()
+        Image.fromarray(img[:, :, ::-1]).save(buf, format="PNG")
+        return base64.b64encode(buf.getvalue()).decode()
+    # frames whose nearest detected face passes the distance gate (20..70) and the blur gate
+    fr = []
+    rng = np.random.default_rng(52)
+    for im in frames(seed=51, n=24, lo=400, hi=640):
+        im = np.clip(im.astype(np.float32) + rng.normal(0, 25, im.shape), 0, 255).astype(np.uint8)      # sharp enough for the blur gate
+        boxes, scores, distances = quality.detect_face(im)
+        if len(boxes):
+            x, y, w, h = boxes[int(np.argmin(distances))]
+            dist = quality.distance_face_to_camera((x, y, x + w, y + h), im.shape[1])
+            if 20 <= dist <= 70 and w > 8 and h > 8 and quality.laplacian_variance_of(im[y:y + h, x:x + w]) >= quality.BLUR_THRESHOLD:
+                fr.append(im)
+    assert len(fr) >= 3, "the synthetic frames give too few usable detections"
+    fr = fr[:6]
+
+    async def run():
+        H = {"X-API-Key": "k"}
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://frhot", timeout=120) as c:
+            for i, im in enumerate(fr):
+                r = await c.post("/create_face_img_base64", headers=H, json={
+                    "img_base64": b64(im), "id": str(i), "name": f"P{i}", "role": "1", "store_id": "S", "is_update": True})
+                assert r.status_code == 201, r.text
+            rs = await asyncio.gather(*[c.post("/face_recog_img_base64", headers=H, json={
+                "img_base64": b64(im), "role": "1", "store_id": "S"}) for im in fr])
+            return [(r.status_code, r.json()) for r in rs]
+    try:
+        answers = asyncio.run(run())
+        for i, (code, body) in enumerate(answers):
+            assert code == 200 and body.get("id") == str(i), (i, code, body)
+        assert app.state.det_batcher.items >= 2 * len(fr)
+    finally:
+        app.state.close()
+    assert quality.models_installed()["extract_faces"] is False
