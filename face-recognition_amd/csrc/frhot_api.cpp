@@ -270,6 +270,9 @@ struct SecondHalfGate {
     virtual ~SecondHalfGate() = default;
 };
 
+constexpr int kShareLayers = 6;     // conv layers 1..6 (conv1_2 .. conv3_3) are launched with a share of the CUs when a batch runs in two parts
+constexpr int kShareMinBatch = 192;
+
 // Enqueue the whole embed pipeline for B crops whose pixels sit at crops_dev.
 int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
                   const int32_t* strides, int B, unsigned flags, float* out_f32, void* out_q, int Dq,
@@ -309,6 +312,18 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
         const int cut = first_part > 0 && first_part < B ? first_part : B / 2;
         const int b0 = part == 0 ? 0 : cut, n = nparts == 1 ? B : (part == 0 ? cut : B - cut);
         hipStream_t hs = part == 0 ? s : c->side_stream;
+        // The launches of the large early layers (through conv3_3) take the part's share of the CUs as
+        // persistent blocks instead of one per CU: the other part's launch of the same layer then runs
+        // beside it from the start, not in the gaps its blocks leave (7.01 -> 6.95 ms per 256 faces);
+        // from conv4_1 on a launch has few rounds of tiles and fills the chip better at full width.
+#ifdef FR_NO_SHARE
+        const int share = 0;
+#else
+        // Not for a host call (its first part runs alone while the second is still being uploaded) and not
+        // for smaller batches, whose launches have too few rounds of tiles for half the CUs
+        // (conv stack at 32 / 64 / 128 faces 1.05 / 1.83 / 3.47 ms without shares, 1.12 / 1.87 / 3.55 with; 192 faces 5.23 against 5.05).
+        const int share = nparts > 1 && !gate && B >= kShareMinBatch ? (256 * n / B + 7) / 8 * 8 : 0;
+#endif
         if (part == 1) {
             if (gate) {
                 const int rc = gate->ready(hs);
@@ -324,10 +339,22 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
                                  c->img_max + b0, c->input_scale, x0, n, hs));
         HIP_TRY(launch_normalize_pack(u8, c->img_max + b0, c->input_scale, x0, n, hs, true));
         if (part == 0 && (c->stage_end(0) || c->stage_begin(1))) return fail(FRHOT_EHIP, "event record failed");
+#ifdef FR_NO_FUSE1      // A/B builds only: the first two layers as two launches (ctx_init allocates act[0] in such a build)
         HIP_TRY(launch_conv1_1(x0, c->w[0], c->bias[0], (char*)c->act[0] + act_elems(kConv[0], b0) * 2, n, hs));
-        for (int l = 1; l < kNumConv; ++l) {
+        {
+            ConvLayerDesc d{kConv[1].hw, kConv[1].cin, kConv[1].cout, kConv[1].pool, kConv[1].opad, 1};
+            HIP_TRY(launch_conv3x3(d, (const char*)c->act[0] + act_elems(kConv[0], b0) * 2, c->w[1], c->bias[1],
+                                   (char*)c->act[1] + act_elems(kConv[1], b0) * 2, c->partial, n, hs));
+        }
+#else
+        // the first two layers are one launch: conv1_1's 6.4 MB per face live only as LDS patches of conv1_2
+        HIP_TRY(launch_conv1_fused(x0, c->w[0], c->bias[0], c->w[1], c->bias[1], (char*)c->act[1] + act_elems(kConv[1], b0) * 2,
+                                   c->partial, n, 1, hs, share));
+#endif
+        for (int l = 2; l < kNumConv; ++l) {
             // layers alternate direction so that each starts on what its predecessor wrote last
             ConvLayerDesc d{kConv[l].hw, kConv[l].cin, kConv[l].cout, kConv[l].pool, kConv[l].opad, l & 1};
+            if (l <= kShareLayers) d.blocks = share;
             HIP_TRY(launch_conv3x3(d, (const char*)c->act[l - 1] + act_elems(kConv[l - 1], b0) * 2, c->w[l], c->bias[l],
                                    (char*)c->act[l] + act_elems(kConv[l], b0) * 2, c->partial, n, hs));
         }
@@ -932,7 +959,11 @@ static int ctx_init(frhot_ctx* c) {
     const size_t x0_bytes = (size_t)B * 226 * 226 * 4 * 2;
     HIP_TRY(hipMalloc(&c->x0, x0_bytes));
     HIP_TRY(hipMemsetAsync(c->x0, 0, x0_bytes, c->stream));
+#ifdef FR_NO_FUSE1
     for (int l = 0; l < kNumConv; ++l) {
+#else
+    for (int l = 1; l < kNumConv; ++l) {     // act[0] (6.4 MB per face) exists only once frhot_debug_read asks for it
+#endif
         const size_t n = act_elems(kConv[l], B) * 2;
         HIP_TRY(hipMalloc(&c->act[l], n));
         HIP_TRY(hipMemsetAsync(c->act[l], 0, n, c->stream));
@@ -1188,6 +1219,18 @@ int frhot_debug_read(frhot_ctx* c, int stage, int B, void* host_out, size_t nbyt
     else if (stage == 30) { src = c->fc6_out; need = (size_t)B * kFcN * 2; }
     else return fail(FRHOT_EINVAL, "unknown stage %d", stage);
     if (nbytes != need) return fail(FRHOT_EINVAL, "stage %d of %d images is %zu bytes, not %zu", stage, B, need, nbytes);
+    if (stage == 10) {
+        if (!c->model) return fail(FRHOT_ESTATE, "frhot_model_load has not been called");
+        // The embed path never stores the first layer's output (it is computed into the second layer's
+        // LDS patches); the stand-alone kernel makes it here from the network input of the last batch.
+        if (!c->act[0]) {
+            const size_t n = act_elems(kConv[0], c->max_batch) * 2;
+            HIP_TRY(hipMalloc(&c->act[0], n));
+            HIP_TRY(hipMemsetAsync(c->act[0], 0, n, c->stream));
+        }
+        HIP_TRY(launch_conv1_1(c->x0, c->w[0], c->bias[0], c->act[0], B, c->stream));
+        src = c->act[0];
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(host_out, src, need, hipMemcpyDeviceToHost));
     return FRHOT_OK;

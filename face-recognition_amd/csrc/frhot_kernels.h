@@ -24,6 +24,7 @@ struct ConvLayerDesc {
     int pool;     // 1: 2x2/2 max-pool fused into the epilogue
     int opad;     // 1: output carries a zero halo of one pixel
     int reverse;  // 1: walk the pixel tiles from the last image to the first (cache reuse across layers)
+    int blocks = 0;  // persistent blocks of the launch (0: one per CU); fewer leave CUs to a launch on another stream
 };
 
 // Resized bytes, per-image maximum, and the fp16 network input [B,226,226,4] of every image whose
@@ -39,6 +40,10 @@ hipError_t launch_normalize_pack(const uint8_t* u8, const int* img_max, float sc
                                  void* x0_f16, int B, hipStream_t s, bool only_undivided = false);
 hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y,
                           int B, hipStream_t s);
+// The first two layers as one launch: conv1_1 computed into the LDS patches of the 224 x 224 x 64 layer
+// (pooled output y [B,114,114,64]); bit-identical to launch_conv1_1 followed by launch_conv3x3.
+hipError_t launch_conv1_fused(const void* x0, const void* w64, const float* bias1, const void* w, const float* bias,
+                              void* y, void* dump, int B, int reverse, hipStream_t s, int blocks = 0);   // blocks: 0 = one per CU
 // `dump`: >= 1 KiB of device scratch (dead lanes of a partial tile store there).
 hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, const float* bias,
                           void* y, void* dump, int B, hipStream_t s);

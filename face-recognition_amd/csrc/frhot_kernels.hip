@@ -1250,12 +1250,25 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
 // fragment covers a 2x8-pixel block (lane&15 -> dy = (l>>1)&1, dx = 2*(l>>2) + (l&1)), and with
 // this sigma every 16-lane group of a ds_read_b128 touches 16 different 16-B slots of the
 // 256-B bank row for every tap shift.
-template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY>
+//
+// FUSE1 (the 224 x 224 layer after the 3-channel one): the patch is not fetched but COMPUTED.
+// x is then the network input [B,226,226,4] and w1/b1 the first layer's [64][64] weights and
+// bias as conv1_1_kernel takes them.  The 324 patch pixels are 21 groups of 16; wave v makes
+// groups v, v+8, v+16 of the NEXT tile's patch while the current tile computes: the three
+// 8-byte tap loads of a group are issued in the L phase of taps 1/3/5 and its eight MFMAs
+// (K = 36 in two 16x16x32, as in conv1_1_kernel), bias, ReLU, fp16 and four ds_write_b64 into
+// the swizzled patch rows run in the M phase of taps 2/4/6.  Patch pixels outside the image
+// are the layer's zero padding, not first-layer outputs: they are written as zeros.  The
+// values are the ones conv1_1_kernel stores (same MFMA order), so the layer's output is
+// bit-identical to the two-kernel path; the 6.4 MB per face between the layers never exists.
+template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY, bool FUSE1 = false>
 __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __restrict__ x,
                                                             const half_t* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             half_t* __restrict__ y, half_t* __restrict__ dump,
-                                                            int batch, int reverse) {
+                                                            int batch, int reverse,
+                                                            const half_t* __restrict__ w1 = nullptr,
+                                                            const float* __restrict__ b1 = nullptr) {
     static_assert(WX * WY == 8 && HW % 16 == 0 && CIN % 64 == 0 && COUT % RY == 0 && RY % 64 == 0, "shape");
     constexpr int PW = 18, NPIECE = 41, PATCH_B = NPIECE * 1024;
     constexpr int CPK = CIN / 64, NKS = 9 * CPK, K = 9 * CIN;
@@ -1307,7 +1320,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const long st = reverse ? (long)batch * TPI - 1 - tile / NT : tile / NT;   // see conv3x3_ring_kernel
         const int b = (int)(st / TPI), rem = (int)(st % TPI);
         const int ty = rem / TPR, tx = rem - ty * TPR;
+        if (FUSE1) return (const char*)x + (((long)b * IW + ty * 16) * IW + tx * 16) * 8;      // 4 channels
         return (const char*)x + ((((long)b * IW + ty * 16) * IW + tx * 16) * CIN + c * 64) * 2;
+    };
+    // which edges of the image the item's tile touches: top, bottom, left, right
+    auto item_edges = [&](long item) __attribute__((always_inline)) -> int {
+        const long tile = wk + (item / CPK) * G;
+        const long st = reverse ? (long)batch * TPI - 1 - tile / NT : tile / NT;
+        const int rem = (int)(st % TPI);
+        const int ty = rem / TPR, tx = rem - ty * TPR;
+        return (ty == 0 ? 1 : 0) | (ty == TPR - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == TPR - 1 ? 8 : 0);
     };
     auto issue_patch = [&](const char* src, int slot, int t) __attribute__((always_inline)) {
         int j = 8 * t + wave;
@@ -1338,6 +1360,74 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         bv[cy] = *(const float4v*)(bias + n0 + wy * TY + (cy >> 1) * 32 + g0 * 8 + (cy & 1) * 4);
         asm volatile("" ::"v"(bv[cy][0]), "v"(bv[cy][1]), "v"(bv[cy][2]), "v"(bv[cy][3]));
     }
+
+    // ---- first-layer producer (FUSE1) ---------------------------------------------------
+    constexpr int NG = (PW * PW + 15) / 16;         // 16-pixel groups of a patch
+    half8 pa0[4], pa1[4];                           // first-layer weights: A fragments of the two K blocks
+    float4v pbv[4];
+    int prel[3], pdst[3], pedge[3];                 // per group: source offset, patch row address, edges the pixel lies beyond
+    int ptap0 = 0, ptap1 = 0;
+    half4 pv0 = {}, pv1 = {}, pv8 = {};             // the group in flight: taps 2g, 2g+1 and 8 of this lane's pixel
+    unsigned pkeep = 0;
+    if constexpr (FUSE1) {
+        static_assert(HW == 224 && CIN == 64 && NT == 1 && CPK == 1, "the fused first layer feeds the 224 x 224 x 64 layer");
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const half_t* wr = w1 + (ct * 16 + l15) * 64;
+            pa0[ct] = *(const half8*)(wr + 8 * g0);
+            pa1[ct] = *(const half8*)(wr + 32 + 8 * g0);
+            pbv[ct] = *(const float4v*)(b1 + ct * 16 + g0 * 4);
+        }
+        const int t0 = 2 * g0, t1 = 2 * g0 + 1;
+        ptap0 = ((t0 / 3) * IW + (t0 % 3)) * 8;
+        ptap1 = ((t1 / 3) * IW + (t1 % 3)) * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int gi = wave + 8 * i;
+            gi = gi < NG ? gi : NG - 1;
+            int P = 16 * gi + l15;
+            P = P < PW * PW ? P : PW * PW - 1;
+            const int py = P / PW, px = P - py * PW;
+            const int sig = (((px >> 1) & 3) << 1) | (py & 1);
+            prel[i] = ((py - 1) * IW + (px - 1)) * 8;       // the pixel's 3 x 3 window starts one up and left of it
+            pedge[i] = (py == 0 ? 1 : 0) | (py == PW - 1 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == PW - 1 ? 8 : 0);
+            pdst[i] = P * 128 + ((((g0 >> 1) ^ sig) << 4) | ((g0 & 1) << 3));
+        }
+    }
+    // loads of group i of the patch of the tile at `base` (its edges: `edges`)
+    auto prod_load = [&](auto ic, const char* base, int edges) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if (i == 2 && wave + 16 >= NG) return;
+        const bool outside = (pedge[i] & edges) != 0;
+        const char* p = base + (outside ? 0 : prel[i]);     // a padding pixel reads the tile's own corner and is zeroed below
+        pv0 = *(const half4*)(p + ptap0);
+        pv1 = *(const half4*)(p + ptap1);
+        pv8 = *(const half4*)(p + (2 * IW + 2) * 8);
+        pkeep = outside ? 0u : 0xffffffffu;
+    };
+    auto prod_compute = [&](auto ic, int slot) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if (i == 2 && wave + 16 >= NG) return;
+        const half_t z = (half_t)0.f;
+        const half8 bf0 = {pv0[0], pv0[1], pv0[2], pv0[3], pv1[0], pv1[1], pv1[2], pv1[3]};
+        const half8 bf1 = {pv8[0], pv8[1], pv8[2], pv8[3], z, z, z, z};     // the weights are zero beyond k = 35
+        float4v pacc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            pacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa0[ct], bf0, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) pacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa1[ct], bf1, pacc[ct], 0, 0, 0);
+        char* const row = patch + slot * PATCH_B;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(pacc[ct][j] + pbv[ct][j], 0.f);
+            uint2 u = __builtin_bit_cast(uint2, o);
+            u.x &= pkeep; u.y &= pkeep;
+            *(uint2*)(row + (pdst[i] ^ (ct << 5))) = u;         // channels 16 ct + 4 g0 ..: chunk (2 ct + g0/2) ^ sigma
+        }
+    };
 
     // ---- fragment read addresses --------------------------------------------------------
     // pixel of this lane inside a 2x8 block, block a = wx*NX + xi at rows 2*(a>>1), columns 8*(a&1)
@@ -1419,7 +1509,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     // a phase handles U of the step's two 32-deep K blocks: 16 MFMAs per wave either way
     constexpr int U = (NX * NY >= 16) ? 1 : 2, NU = 2 / U;
     half8 fx[U][NX], fy[U][NY];
-    auto phase_L = [&](auto tapc, auto uc, int chunk, long s, int slot, const char* nsrc) __attribute__((always_inline)) {
+    static_assert(!FUSE1 || (RES && NU == 1 && DEFER), "the fused producer's place in the schedule");
+    auto phase_L = [&](auto tapc, auto uc, int chunk, long s, int slot, const char* nsrc, int nedges) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value, u = decltype(uc)::value;
         constexpr int r = tap / 3, sx = tap - 3 * r;
         // the step's LDS-DMA issues are spread over its L phases (an issue costs the wave tens of
@@ -1433,7 +1524,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
 #endif
 #if !(FR_DBG & 2)
         if (u == NU - 1) {
-            if (tap < 6) issue_patch(nsrc, slot ^ 1, tap);
+            if constexpr (FUSE1) {
+                if (tap == 1) prod_load(std::integral_constant<int, 0>{}, nsrc, nedges);
+                if (tap == 3) prod_load(std::integral_constant<int, 1>{}, nsrc, nedges);
+                if (tap == 5) prod_load(std::integral_constant<int, 2>{}, nsrc, nedges);
+            } else {
+                if (tap < 6) issue_patch(nsrc, slot ^ 1, tap);
+            }
         }
 #endif
         const char* const pb = patch + slot * PATCH_B;
@@ -1452,8 +1549,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
             }
         }
     };
-    auto phase_M = [&](auto tapc, auto uc, int chunk, long tile, long s) __attribute__((always_inline)) {
+    auto phase_M = [&](auto tapc, auto uc, int chunk, long tile, long s, int slot) __attribute__((always_inline)) {
         constexpr int tap = decltype(tapc)::value, u = decltype(uc)::value;
+#if !(FR_DBG & 2)
+        if constexpr (FUSE1) {
+            // (group B's M phase of tap 8 runs beside group A's first reads of the new patch: nothing after tap 7)
+            if (tap == 2) prod_compute(std::integral_constant<int, 0>{}, slot ^ 1);
+            if (tap == 4) prod_compute(std::integral_constant<int, 1>{}, slot ^ 1);
+            if (tap == 6) prod_compute(std::integral_constant<int, 2>{}, slot ^ 1);
+        }
+#endif
 #if defined(FR_W_IN_M)
         if (u == 0 && NU == 2) {
             if (!RES) {
@@ -1470,6 +1575,10 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
                 for (int b2 = 0; b2 < NX; ++b2)
                     acc[a][b2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fy[k2][a], fx[k2][b2], acc[a][b2], 0, 0, 0);
 #endif
+        if constexpr (FUSE1) {
+            // the patch rows written above must be in LDS before the barrier that ends this phase
+            if (tap == 2 || tap == 4 || tap == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if (u != NU - 1) return;
         if (DEFER) {
             if (chunk == 0) {
@@ -1499,8 +1608,15 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
     // ---- prologue -------------------------------------------------------------------------
     {
         const char* src0 = item_src(0);
+        if constexpr (FUSE1) {
+            const int e0 = item_edges(0);
+            prod_load(std::integral_constant<int, 0>{}, src0, e0); prod_compute(std::integral_constant<int, 0>{}, 0);
+            prod_load(std::integral_constant<int, 1>{}, src0, e0); prod_compute(std::integral_constant<int, 1>{}, 0);
+            prod_load(std::integral_constant<int, 2>{}, src0, e0); prod_compute(std::integral_constant<int, 2>{}, 0);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) issue_patch(src0, 0, t);
+            for (int t = 0; t < 6; ++t) issue_patch(src0, 0, t);
+        }
         if (RES) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) issue_w(ks, ks);
@@ -1508,7 +1624,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) issue_w(ks, ks % NKS);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
@@ -1537,22 +1653,23 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         // the item after the last re-fetches the last item's patch into the idle slot: every
         // step then issues the same number of loads, which the counted waits rely on
         const char* nsrc = item_src(item + 1 < n_items ? item + 1 : item);
+        const int nedges = FUSE1 ? item_edges(item + 1 < n_items ? item + 1 : item) : 0;
         auto step = [&](auto tapc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tapc)::value;
             FR_STAMP(st_a);
-            phase_L(tapc, std::integral_constant<int, 0>{}, chunk, s, slot, nsrc);
+            phase_L(tapc, std::integral_constant<int, 0>{}, chunk, s, slot, nsrc, nedges);
             if (NU == 2) {
                 FR_STAMP(st_b);
                 phase_barrier();
                 FR_STAMP(st_c);
-                phase_M(tapc, std::integral_constant<int, 0>{}, chunk, tile, s);
+                phase_M(tapc, std::integral_constant<int, 0>{}, chunk, tile, s, slot);
                 FR_STAMP(st_d);
                 phase_barrier();
                 FR_STAMP(st_e);
 #if FR_DBG & 8
                 sum_L += st_b - st_a; sum_B1 += st_c - st_b; sum_M += st_d - st_c; sum_B2 += st_e - st_d; ++n_units;
 #endif
-                phase_L(tapc, std::integral_constant<int, NU - 1>{}, chunk, s, slot, nsrc);
+                phase_L(tapc, std::integral_constant<int, NU - 1>{}, chunk, s, slot, nsrc, nedges);
                 FR_STAMP(st_a);
 #if FR_DBG & 8
                 sum_L2 += st_a - st_e;
@@ -1565,7 +1682,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
             // l(s), with l(t) = NPY weight pieces + one patch piece in taps 0..5 and e(t) = the
             // epilogue stores of M(t).
             if (RES) {
-                if (tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tap == 8 && !FUSE1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next patch has landed
             } else {
                 constexpr int l1 = NPY + ((tap + 8) % 9 < 6 ? 1 : 0), l0 = NPY + (tap < 6 ? 1 : 0);
                 if (s + 4 >= S) {
@@ -1586,7 +1703,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
             FR_STAMP(st_b);
             phase_barrier();
             FR_STAMP(st_c);
-            phase_M(tapc, std::integral_constant<int, NU - 1>{}, chunk, tile, s);
+            phase_M(tapc, std::integral_constant<int, NU - 1>{}, chunk, tile, s, slot);
             FR_STAMP(st_d);
             phase_barrier();
             FR_STAMP(st_e);
@@ -3377,10 +3494,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino_kernel(const half_t* __restr
 // ---------------------------------------------------------------- launch ---
 #define FR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY>
+template <int HW, int CIN, int COUT, bool POOL, int RY, int WX, int WY, bool FUSE1 = false>
 static hipError_t launch_patch_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
-                                    int reverse, hipStream_t s, bool set_attr_only) {
-    auto kern = conv3x3_patch_kernel<HW, CIN, COUT, POOL, RY, WX, WY>;
+                                    int reverse, hipStream_t s, bool set_attr_only, const void* w1 = nullptr,
+                                    const float* b1 = nullptr, int blocks = 0) {
+    auto kern = conv3x3_patch_kernel<HW, CIN, COUT, POOL, RY, WX, WY, FUSE1>;
     constexpr int patch2 = 2 * 41 * 1024, nks = 9 * CIN / 64, yb = RY * 128;
     constexpr bool res = nks * yb + patch2 <= 160 * 1024;
     constexpr int lds = patch2 + (res ? nks : 4) * yb;
@@ -3389,17 +3507,17 @@ static hipError_t launch_patch_inst(const void* x, const void* w, const float* b
         return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     constexpr int NT = COUT / RY;
     const long ntiles = (long)B * (HW / 16) * (HW / 16) * NT;
-    long grid = 256;                       // one walker per CU; a multiple of COUT / RY
+    long grid = blocks > 0 ? blocks / NT * NT : 256;     // one walker per CU; a multiple of COUT / RY
     if (grid > ntiles) grid = ntiles;      // ntiles is a multiple of NT
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
-                       (half_t*)y, (half_t*)dump, B, reverse);
+                       (half_t*)y, (half_t*)dump, B, reverse, (const half_t*)w1, b1);
     FR_CHECK_LAUNCH();
     return hipSuccess;
 }
 
 template <int HW, int CIN, int COUT, bool POOL, int OPAD, int RY, int WX, int WY>
 static hipError_t launch_conv_inst(const void* x, const void* w, const float* bias, void* y, void* dump, int B,
-                                   int reverse, hipStream_t s, bool set_attr_only) {
+                                   int reverse, hipStream_t s, bool set_attr_only, int blocks = 0) {
     using Core = GemmCore8<256, RY, WX, WY, false>;
     auto kern = conv3x3_ring_kernel<HW, CIN, COUT, POOL, OPAD, RY, WX, WY>;
     constexpr int lds = Core::LDS;
@@ -3409,7 +3527,7 @@ static hipError_t launch_conv_inst(const void* x, const void* w, const float* bi
     // the kernel addresses its input with 32-bit byte offsets per lane
     if ((unsigned long long)B * (HW + 2) * (HW + 2) * CIN * 2ull >= (1ull << 32)) return hipErrorInvalidValue;
     const long ntiles = ((M + 255) / 256) * (COUT / RY);
-    long grid = 256;                       // one walker per CU; a multiple of COUT / RY
+    long grid = blocks > 0 ? blocks / (COUT / RY) * (COUT / RY) : 256;     // one walker per CU; a multiple of COUT / RY
     if (grid > ntiles) grid = (ntiles + 1) & ~1L;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, (const half_t*)x, (const half_t*)w, bias,
                        (half_t*)y, (half_t*)dump, B, reverse);
@@ -3421,7 +3539,7 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
                                 void* dump, int B, hipStream_t s, bool attr) {
 #define FR_PATCH(HW, CIN, COUT, POOL, RY, WX, WY)                                                            \
     if (d.hw == HW && d.cin == CIN && d.cout == COUT && d.pool == (POOL ? 1 : 0) && d.opad == 1)              \
-        return launch_patch_inst<HW, CIN, COUT, POOL, RY, WX, WY>(x, w, bias, y, dump, B, d.reverse, s, attr);
+        return launch_patch_inst<HW, CIN, COUT, POOL, RY, WX, WY>(x, w, bias, y, dump, B, d.reverse, s, attr, nullptr, nullptr, d.blocks);
     FR_PATCH(224, 64, 64, true, 64, 4, 2)
     FR_PATCH(112, 64, 128, false, 128, 4, 2)
     FR_PATCH(112, 128, 128, true, 128, 4, 2)
@@ -3445,7 +3563,7 @@ static hipError_t conv_dispatch(const ConvLayerDesc& d, const void* x, const voi
         } else if (((long)B * HW * HW + 255) / 256 * (COUT / 256) <= 128) {                                   \
             return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 128, 4, 2>(x, w, bias, y, dump, B, d.reverse, s, attr); \
         }                                                                                                     \
-        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 256, 2, 4>(x, w, bias, y, dump, B, d.reverse, s, attr);     \
+        return launch_conv_inst<HW, CIN, COUT, POOL, OPAD, 256, 2, 4>(x, w, bias, y, dump, B, d.reverse, s, attr, d.blocks);     \
     }
     FR_CONV(56, 128, 256, false, 1)
     FR_CONV(56, 256, 256, false, 1)
@@ -3511,6 +3629,13 @@ hipError_t launch_conv3x3(const ConvLayerDesc& d, const void* x, const void* w, 
                           void* dump, int B, hipStream_t s) {
     if (B <= 0 || !x || !w || !bias || !y || !dump) return hipErrorInvalidValue;
     return conv_dispatch(d, x, w, bias, y, dump, B, s, false);
+}
+
+hipError_t launch_conv1_fused(const void* x0, const void* w64, const float* bias1, const void* w, const float* bias,
+                              void* y, void* dump, int B, int reverse, hipStream_t s, int blocks) {
+    if (B <= 0 || !x0 || !w64 || !bias1 || !w || !bias || !y || !dump || blocks < 0 || blocks > 256) return hipErrorInvalidValue;
+    return launch_patch_inst<224, 64, 64, true, 64, 4, 2, true>(x0, w, bias, y, dump, B, reverse, s, false, w64, bias1,
+                                                                blocks);
 }
 
 hipError_t launch_conv1_1(const void* x0, const void* w64, const float* bias, void* y, int B, hipStream_t s) {
@@ -3991,8 +4116,11 @@ hipError_t kernels_init() {
         if (e != hipSuccess && e != hipErrorInvalidValue) return e;      // invalid value: no Winograd form of this layer
 #endif
     }
-    hipError_t e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);
+    hipError_t e = launch_patch_inst<224, 64, 64, true, 64, 4, 2, true>(nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                                                                        nullptr, true);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);
     if (e != hipSuccess) return e;
     static const int combos[][2] = {{5, 64}, {5, 128}, {5, 256}, {10, 64}, {10, 128}, {16, 64}};
     for (const auto& c : combos)

@@ -107,7 +107,10 @@ int frhot_embed_dev(frhot_ctx* ctx, const void* crops_dev, const int64_t* offset
  * stage 0: uint8 [B,224,224,3] resized+padded image (before float conversion);
  * stage 1: fp16 [B,226,226,4] network input (halo and 4th channel zero);
  * stage 10+l (l = 0..12): fp16 output of conv layer l (conv1_1 .. conv5_3, after its
- *   pooling where it has one), [B,P,P,C] with a one-pixel zero halo except l = 12;
+ *   pooling where it has one), [B,P,P,C] with a one-pixel zero halo except l = 12; the embed path
+ *   computes conv1_1 inside conv1_2's kernel and never stores it, so stage 10 is made on request from
+ *   stage 1 by the stand-alone first-layer kernel (same arithmetic, same bits), into a buffer of
+ *   6.4 MB per face of max_batch that is allocated at the first such request;
  * stage 30: fp16 [B,4096] fc6 output (input-scaled like every activation).
  */
 int frhot_debug_read(frhot_ctx* ctx, int stage, int B, void* host_out, size_t nbytes);

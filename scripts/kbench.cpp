@@ -2,10 +2,14 @@
 // Times each conv layer of the VGG-Face stack and the gallery scan at several shapes with HIP
 // events, on random data, and prints ms + TFLOP/s or GB/s per kernel.
 //   kbench conv [B]            every conv layer at batch B (default 256)
+//   kbench fuse [B]            the first two layers as two launches and as one, outputs compared (exit 1 if they differ)
+//   kbench stack2 [B]          the conv stack as two halves on two streams, first two layers unfused / fused
+//                              (KBENCH_BLOCKS, KBENCH_LAYERS, KBENCH_SYNC, KBENCH_V: see bench_stack2)
 //   kbench scan                the scan at the benchmark shapes
 //   kbench all
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -254,6 +258,203 @@ static void bench_conv(int B) {
     CK(hipStreamDestroy(s));
 }
 
+// The first two layers as two launches against the fused one: same input, outputs compared bit for bit, both timed.
+static void bench_fuse(int B) {
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    void* dump;
+    CK(hipMalloc(&dump, 4096));
+    void* x0 = dev_random_f16((size_t)B * 226 * 226 * 4, 8.0f, 1);
+    void* w1 = dev_random_f16(64 * 64, 0.1f, 2);
+    void* w2 = dev_random_f16((size_t)64 * 9 * 64, 0.05f, 40);
+    if (getenv("KBENCH_IMAGE")) {
+        // an image-like input: smooth values, zero fourth channel and halo, first-layer weights zero beyond k = 35
+        std::vector<uint16_t> img((size_t)226 * 226 * 4, 0);
+        uint64_t sd = 5;
+        for (int yy = 1; yy <= 224; ++yy)
+            for (int xx = 1; xx <= 224; ++xx)
+                for (int c = 0; c < 3; ++c) {
+                    const float v = 7.0f * (0.5f + 0.4f * sinf(0.05f * xx + c) * cosf(0.04f * yy)) + 0.3f * ((float)(sm64(sd) >> 40) / 16777216.0f);
+                    img[((size_t)yy * 226 + xx) * 4 + c] = f2h(v - 6.0f);
+                }
+        for (int b = 0; b < B; ++b) CK(hipMemcpy((char*)x0 + (size_t)b * img.size() * 2, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+        std::vector<uint16_t> hw(64 * 64);
+        CK(hipMemcpy(hw.data(), w1, hw.size() * 2, hipMemcpyDeviceToHost));
+        for (int r = 0; r < 64; ++r)
+            for (int k = 36; k < 64; ++k) hw[r * 64 + k] = 0;
+        CK(hipMemcpy(w1, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
+    std::vector<float> hb(128);
+    for (int i = 0; i < 128; ++i) hb[i] = 0.05f * (float)((i * 37) % 21 - 10);
+    float* bias;
+    CK(hipMalloc((void**)&bias, 128 * 4));
+    CK(hipMemcpy(bias, hb.data(), 128 * 4, hipMemcpyHostToDevice));
+    const size_t mid = (size_t)B * 226 * 226 * 64, yout = (size_t)B * 114 * 114 * 64;
+    void *ym, *y0, *y1;
+    CK(hipMalloc(&ym, mid * 2));
+    CK(hipMalloc(&y0, yout * 2));
+    CK(hipMalloc(&y1, yout * 2));
+    CK(hipMemset(ym, 0, mid * 2));
+    CK(hipMemset(y0, 0, yout * 2));
+    CK(hipMemset(y1, 0xff, yout * 2));
+    const ConvLayerDesc d{224, 64, 64, 1, 1, 0};
+    for (int rev = 0; rev < 2; ++rev) {
+        ConvLayerDesc dr = d;
+        dr.reverse = rev;
+        CK(launch_conv1_1(x0, w1, bias, ym, B, s));
+        CK(launch_conv3x3(dr, ym, w2, bias + 64, y0, dump, B, s));
+        CK(launch_conv1_fused(x0, w1, bias, w2, bias + 64, y1, dump, B, rev, s));
+        CK(hipStreamSynchronize(s));
+        std::vector<uint16_t> h0(yout), h1(yout);
+        CK(hipMemcpy(h0.data(), y0, yout * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h1.data(), y1, yout * 2, hipMemcpyDeviceToHost));
+        size_t diff = 0, nz = 0, first = yout;
+        for (size_t b = 0; b < (size_t)B; ++b)
+            for (int yy = 1; yy <= 112; ++yy)
+                for (int xx = 1; xx <= 112; ++xx)
+                    for (int c = 0; c < 64; ++c) {
+                        const size_t i = ((b * 114 + yy) * 114 + xx) * 64 + c;
+                        if (h0[i] != h1[i]) { ++diff; if (first == yout) first = i; }
+                        nz += h0[i] != 0;
+                    }
+        printf("fused vs two launches (reverse %d): %zu of %zu interior values differ, %.2f nonzero", rev, diff,
+               (size_t)B * 112 * 112 * 64, (double)nz / ((double)B * 112 * 112 * 64));
+        if (diff) {
+            const size_t c = first % 64, xx = first / 64 % 114, yy = first / 64 / 114 % 114, b = first / 64 / 114 / 114;
+            printf("; first at image %zu y %zu x %zu channel %zu", b, yy, xx, c);
+        }
+        printf("\n");
+        if (diff) exit(1);
+    }
+    const float t1 = time_ms([&] { CK(launch_conv1_1(x0, w1, bias, ym, B, s)); }, 3, 40, s);
+    const float t2 = time_ms([&] { CK(launch_conv3x3(d, ym, w2, bias + 64, y0, dump, B, s)); }, 3, 40, s);
+    const float t12 = time_ms([&] { CK(launch_conv1_1(x0, w1, bias, ym, B, s)); CK(launch_conv3x3(d, ym, w2, bias + 64, y0, dump, B, s)); }, 3, 40, s);
+    const float tf = time_ms([&] { CK(launch_conv1_fused(x0, w1, bias, w2, bias + 64, y1, dump, B, 0, s)); }, 3, 40, s);
+    {
+        // the library's schedule: the batch as two halves on two streams, each half its own launches
+        hipStream_t s2;
+        CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        hipEvent_t fork, join;
+        CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        const int h = B / 2;
+        const size_t x0h = (size_t)h * 226 * 226 * 4 * 2, ymh = (size_t)h * 226 * 226 * 64 * 2, yh = (size_t)h * 114 * 114 * 64 * 2;
+        for (int fused = 0; fused < 2 && h > 0; ++fused)
+            for (int rev = 0; rev < 2; ++rev) {
+                ConvLayerDesc dr = d;
+                dr.reverse = rev;
+                const float t = time_ms([&] {
+                    CK(hipEventRecord(fork, s));
+                    CK(hipStreamWaitEvent(s2, fork, 0));
+                    for (int part = 0; part < 2; ++part) {
+                        hipStream_t hs = part ? s2 : s;
+                        const char* xi = (const char*)x0 + part * x0h;
+                        char* mi = (char*)ym + part * ymh;
+                        char* yi = (char*)(fused ? y1 : y0) + part * yh;
+                        if (fused) CK(launch_conv1_fused(xi, w1, bias, w2, bias + 64, yi, dump, h, rev, hs));
+                        else { CK(launch_conv1_1(xi, w1, bias, mi, h, hs)); CK(launch_conv3x3(dr, mi, w2, bias + 64, yi, dump, h, hs)); }
+                    }
+                    CK(hipEventRecord(join, s2));
+                    CK(hipStreamWaitEvent(s, join, 0));
+                }, 3, 40, s);
+                printf("two halves on two streams, %s, reverse %d: %.3f ms\n", fused ? "fused" : "two launches", rev, t);
+            }
+        CK(hipStreamDestroy(s2));
+    }
+    const float tfr = time_ms([&] { CK(launch_conv1_fused(x0, w1, bias, w2, bias + 64, y1, dump, B, 1, s)); }, 3, 40, s);
+    printf("fused, reverse 1: %.3f ms\n", tfr);
+    const double fl = 2.0 * B * 224 * 224 * 9.0 * 64 * 64;
+    printf("batch %d: conv1_1 %.3f ms, conv1_2 %.3f ms (%.0f TF), back to back %.3f ms; fused %.3f ms (%.0f TF of the second layer)\n", B,
+           t1, t2, fl / t2 / 1e9, t12, tf, fl / tf / 1e9);
+    CK(hipFree(x0)); CK(hipFree(w1)); CK(hipFree(w2)); CK(hipFree(bias)); CK(hipFree(ym)); CK(hipFree(y0)); CK(hipFree(y1));
+    CK(hipFree(dump));
+    CK(hipStreamDestroy(s));
+}
+
+// The conv stack as the library schedules it: two halves of the batch on two streams, every layer a
+// launch per half; the first two layers as two launches or as the fused one.  KBENCH_LAYERS=n stops after n layers.
+static void bench_stack2(int B) {
+    static const ConvLayerDesc L[] = {
+        {224, 64, 64, 1, 1},  {112, 64, 128, 0, 1}, {112, 128, 128, 1, 1}, {56, 128, 256, 0, 1},
+        {56, 256, 256, 0, 1}, {56, 256, 256, 1, 1}, {28, 256, 512, 0, 1},  {28, 512, 512, 0, 1},
+        {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
+    };
+    const int nl = getenv("KBENCH_LAYERS") ? atoi(getenv("KBENCH_LAYERS")) : 12;
+    hipStream_t s, s2;
+    CK(hipStreamCreate(&s));
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t fork, join;
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    void* dump;
+    CK(hipMalloc(&dump, 4096));
+    void* x0 = dev_random_f16((size_t)B * 226 * 226 * 4, 8.0f, 1);
+    void* w1 = dev_random_f16(64 * 64, 0.1f, 2);
+    float* bias;
+    CK(hipMalloc((void**)&bias, 512 * 4));
+    CK(hipMemset(bias, 0, 512 * 4));
+    void* act[13];
+    size_t per[13];
+    per[0] = (size_t)226 * 226 * 64 * 2;
+    void* w[12];
+    for (int i = 0; i < 12; ++i) {
+        const ConvLayerDesc& d = L[i];
+        const int ho = d.pool ? d.hw / 2 : d.hw;
+        per[i + 1] = (size_t)(ho + 2 * d.opad) * (ho + 2 * d.opad) * d.cout * 2;
+        // uniform with the He standard deviation sqrt(2 / fan_in): activations keep their scale through the stack
+        w[i] = dev_random_f16((size_t)d.cout * 9 * d.cin, sqrtf(3.0f * 2.0f / (9.0f * d.cin)), 40 + i);
+    }
+    for (int i = 0; i < 13; ++i) {
+        CK(hipMalloc(&act[i], per[i] * B));
+        CK(hipMemset(act[i], 0, per[i] * B));
+    }
+    const int h = B / 2;
+    // KBENCH_V, variants of the fused schedule: 2 = the second half's first launch waits for the first half's,
+    // 4 = one launch for the whole batch before the fork
+    const int variant = getenv("KBENCH_V") ? atoi(getenv("KBENCH_V")) : 0;
+    hipEvent_t first_done;
+    CK(hipEventCreateWithFlags(&first_done, hipEventDisableTiming));
+    int tab[12] = {};       // KBENCH_BLOCKS: persistent blocks per launch of conv1_2 (or the fused launch) .. conv5_3, comma separated (0: one per CU)
+    {
+        const char* e = getenv("KBENCH_BLOCKS");
+        for (int k = 0; k < 12 && e && *e; ++k) { tab[k] = atoi(e); e = strchr(e, ','); if (e) ++e; else break; }
+    }
+    for (int fused = 0; fused < 2; ++fused) {
+        const float t = time_ms([&] {
+            if (fused && variant == 4) CK(launch_conv1_fused(x0, w1, bias, w[0], bias, act[1], dump, B, 1, s));
+            CK(hipEventRecord(fork, s));
+            CK(hipStreamWaitEvent(s2, fork, 0));
+            for (int part = 0; part < 2; ++part) {
+                hipStream_t hs = part ? s2 : s;
+                const char* xi = (const char*)x0 + (size_t)part * h * 226 * 226 * 8;
+                int first = 0;
+                if (fused) {
+                    if (variant == 2 && part == 1) CK(hipStreamWaitEvent(hs, first_done, 0));
+                    if (variant != 4)
+                        CK(launch_conv1_fused(xi, w1, bias, w[0], bias, (char*)act[1] + part * h * per[1], dump, h, 1, hs,
+                                              tab[0]));
+                    if (variant == 2 && part == 0) CK(hipEventRecord(first_done, hs));
+                    first = 1;
+                } else {
+                    CK(launch_conv1_1(xi, w1, bias, (char*)act[0] + part * h * per[0], h, hs));
+                }
+                for (int i = first; i < nl; ++i) {
+                    ConvLayerDesc d = L[i];
+                    d.reverse = (i + 1) & 1;
+                    d.blocks = tab[i];
+                    CK(launch_conv3x3(d, (const char*)act[i] + part * h * per[i], w[i], bias, (char*)act[i + 1] + part * h * per[i + 1],
+                                      dump, h, hs));
+                }
+            }
+            CK(hipEventRecord(join, s2));
+            CK(hipStreamWaitEvent(s, join, 0));
+            if (getenv("KBENCH_SYNC")) CK(hipStreamSynchronize(s));       // every pass starts on an idle GPU
+        }, 3, getenv("KBENCH_ITERS") ? atoi(getenv("KBENCH_ITERS")) : 30, s);       // (30 passes are a burst: clocks settle lower after about a second)
+        printf("conv stack (%d layers after the first), two halves of %d on two streams, %s: %.3f ms\n", nl, h,
+               fused ? "first two layers fused" : "first two layers as two launches", t);
+    }
+}
+
 static void bench_scan_one(long N, int D, int Bq, int k, int use_keys, hipStream_t s) {
     const size_t padded = ((size_t)N + 255) & ~(size_t)255;
     void* g;
@@ -402,6 +603,8 @@ int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     CK(kernels_init());
     if (!strcmp(what, "conv") || !strcmp(what, "all")) bench_conv(argc > 2 ? atoi(argv[2]) : 256);
+    if (!strcmp(what, "fuse")) bench_fuse(argc > 2 ? atoi(argv[2]) : 256);
+    if (!strcmp(what, "stack2")) bench_stack2(argc > 2 ? atoi(argv[2]) : 256);
 #if FR_WINOGRAD
     if (!strcmp(what, "wino")) bench_wino(argc > 2 ? atoi(argv[2]) : 256);
 #endif
