@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: every batch size gives every crop the descriptor it gets in a batch of 16, bit for bit
-(partial last tiles of every conv layer, both tile walk directions, split-K FC with few rows)."""
+(partial last tiles of every conv layer, both tile walk directions, split-K FC with few rows), through the host call and through
+the device-pointer call (whose large batches launch the early layers with a share of the CUs per half)."""
 import os
 import sys
 
@@ -9,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "face-recognition_amd")):
     sys.path.insert(0, p)
 
 import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from frhot import synth  # noqa: E402
 from frhot.engine import Context  # noqa: E402
@@ -30,6 +32,13 @@ def main():
         idx = rng.integers(0, 64, size=b)
         got = big.embed([pool[i] for i in idx], gamma=True)
         assert np.array_equal(got, want[idx]), f"batch {b}: descriptors differ"
+        buf, offsets, hw, strides = synth.pack_crops([pool[i] for i in idx])
+        crops_dev = torch.from_numpy(buf).to("cuda:0")
+        out = torch.empty((b, 4096), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        big.embed_dev(crops_dev.data_ptr(), offsets, hw, strides, Context.flags(gamma=True, flip=True), out.data_ptr(), None)
+        big.sync()
+        assert np.array_equal(out.cpu().numpy(), want[idx]), f"batch {b}: descriptors of the device-pointer call differ"
         print(f"batch {b}: ok", flush=True)
     big.close()
     print("fuzz_batches: all batch sizes bit-identical")

@@ -153,6 +153,7 @@ def test_embed_full_batch(gpu_ctx, weights_f32):
     directions, full-width channel tiles in the later layers): every descriptor equals, bit for bit,
     the one the same crop gets in a small batch (which runs those layers with the narrower channel
     tiles of small launches), and a sample meets the cosine tolerance against the oracle."""
+    import torch
     from frhot import synth
     from frhot.engine import Context
     from frhot.weights import pack_blob
@@ -161,6 +162,15 @@ def test_embed_full_batch(gpu_ctx, weights_f32):
     big = Context(device=0, max_batch=256)
     big.load_model(pack_blob(weights_f32), input_scale=1.0 / 16.0)
     got = big.embed(imgs, gamma=True)
+    # the device-pointer call runs its two halves side by side (the early layers with half of the
+    # persistent blocks each) where the host call starts the second half when its crops arrive: same bits
+    buf, offsets, hw, strides = synth.pack_crops(imgs)
+    crops_dev = torch.from_numpy(buf).to("cuda:0")
+    out = torch.empty((256, 4096), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    big.embed_dev(crops_dev.data_ptr(), offsets, hw, strides, Context.flags(gamma=True, flip=True), out.data_ptr(), None)
+    big.sync()
+    assert np.array_equal(out.cpu().numpy(), got)
     big.close()
     assert got.shape == (256, 4096) and np.isfinite(got).all()
     assert np.allclose(np.linalg.norm(got.astype(np.float64), axis=1), 1.0, atol=1e-5)
