@@ -1253,7 +1253,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
 //
 // FUSE1 (the 224 x 224 layer after the 3-channel one): the patch is not fetched but COMPUTED.
 // x is then the network input [B,226,226,4] and w1/b1 the first layer's [64][64] weights and
-// bias as conv1_1_kernel takes them.  The 324 patch pixels are 21 groups of 16; wave v makes
+// bias as conv1_1_kernel takes them.  The 324 patch pixels are 21 groups of 16 (2 x 8 blocks,
+// and the last two columns); wave v makes
 // groups v, v+8, v+16 of the NEXT tile's patch while the current tile computes: the three
 // 8-byte tap loads of a group are issued in the L phase of taps 1/3/5 and its eight MFMAs
 // (K = 36 in two 16x16x32, as in conv1_1_kernel), bias, ReLU, fp16 and four ds_write_b64 into
@@ -1381,13 +1382,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const half_t* __rest
         const int t0 = 2 * g0, t1 = 2 * g0 + 1;
         ptap0 = ((t0 / 3) * IW + (t0 % 3)) * 8;
         ptap1 = ((t1 / 3) * IW + (t1 % 3)) * 8;
+        // A group's 16 pixels: groups 0..17 are the 2 x 8 blocks of columns 0..15 (the 16 lanes of a k-group then
+        // write 16 different 16-byte slots of the 256-byte bank row: pixel parity = px & 1, sigma from px >> 1 and
+        // py & 1), groups 18..20 the two last columns, eight rows each (the last one two rows, written twice over).
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int gi = wave + 8 * i;
             gi = gi < NG ? gi : NG - 1;
-            int P = 16 * gi + l15;
-            P = P < PW * PW ? P : PW * PW - 1;
-            const int py = P / PW, px = P - py * PW;
+            int py, px;
+            if (gi < 18) { py = 2 * (gi >> 1) + (l15 >> 3); px = 8 * (gi & 1) + (l15 & 7); }
+            else { py = 8 * (gi - 18) + (l15 >> 1); px = 16 + (l15 & 1); if (py >= PW) py = 16 + ((l15 >> 1) & 1); }
+            const int P = py * PW + px;
             const int sig = (((px >> 1) & 3) << 1) | (py & 1);
             prel[i] = ((py - 1) * IW + (px - 1)) * 8;       // the pixel's 3 x 3 window starts one up and left of it
             pedge[i] = (py == 0 ? 1 : 0) | (py == PW - 1 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == PW - 1 ? 8 : 0);
