@@ -380,12 +380,16 @@ static void bench_stack2(int B) {
         {28, 512, 512, 1, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 0, 1}, {14, 512, 512, 1, 0},
     };
     const int nl = getenv("KBENCH_LAYERS") ? atoi(getenv("KBENCH_LAYERS")) : 12;
-    hipStream_t s, s2;
+    const int nparts = getenv("KBENCH_PARTS") ? atoi(getenv("KBENCH_PARTS")) : 2;      // 2..8 equal parts, one stream each
+    if (nparts < 2 || nparts > 8 || B % nparts) { fprintf(stderr, "KBENCH_PARTS must divide the batch\n"); exit(1); }
+    hipStream_t s, side[8];
     CK(hipStreamCreate(&s));
-    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    hipEvent_t fork, join;
+    hipEvent_t fork, join[8];
     CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    for (int p = 1; p < nparts; ++p) {
+        CK(hipStreamCreateWithFlags(&side[p], hipStreamNonBlocking));
+        CK(hipEventCreateWithFlags(&join[p], hipEventDisableTiming));
+    }
     void* dump;
     CK(hipMalloc(&dump, 4096));
     void* x0 = dev_random_f16((size_t)B * 226 * 226 * 4, 8.0f, 1);
@@ -408,7 +412,7 @@ static void bench_stack2(int B) {
         CK(hipMalloc(&act[i], per[i] * B));
         CK(hipMemset(act[i], 0, per[i] * B));
     }
-    const int h = B / 2;
+    const int h = B / nparts;
     // KBENCH_V, variants of the fused schedule: 2 = the second half's first launch waits for the first half's,
     // 4 = one launch for the whole batch before the fork
     const int variant = getenv("KBENCH_V") ? atoi(getenv("KBENCH_V")) : 0;
@@ -423,9 +427,9 @@ static void bench_stack2(int B) {
         const float t = time_ms([&] {
             if (fused && variant == 4) CK(launch_conv1_fused(x0, w1, bias, w[0], bias, act[1], dump, B, 1, s));
             CK(hipEventRecord(fork, s));
-            CK(hipStreamWaitEvent(s2, fork, 0));
-            for (int part = 0; part < 2; ++part) {
-                hipStream_t hs = part ? s2 : s;
+            for (int p = 1; p < nparts; ++p) CK(hipStreamWaitEvent(side[p], fork, 0));
+            for (int part = 0; part < nparts; ++part) {
+                hipStream_t hs = part ? side[part] : s;
                 const char* xi = (const char*)x0 + (size_t)part * h * 226 * 226 * 8;
                 int first = 0;
                 if (fused) {
@@ -446,11 +450,13 @@ static void bench_stack2(int B) {
                                       dump, h, hs));
                 }
             }
-            CK(hipEventRecord(join, s2));
-            CK(hipStreamWaitEvent(s, join, 0));
+            for (int p = 1; p < nparts; ++p) {
+                CK(hipEventRecord(join[p], side[p]));
+                CK(hipStreamWaitEvent(s, join[p], 0));
+            }
             if (getenv("KBENCH_SYNC")) CK(hipStreamSynchronize(s));       // every pass starts on an idle GPU
         }, 3, getenv("KBENCH_ITERS") ? atoi(getenv("KBENCH_ITERS")) : 30, s);       // (30 passes are a burst: clocks settle lower after about a second)
-        printf("conv stack (%d layers after the first), two halves of %d on two streams, %s: %.3f ms\n", nl, h,
+        printf("conv stack (%d layers after the first), %d parts of %d faces on as many streams, %s: %.3f ms\n", nl, nparts, h,
                fused ? "first two layers fused" : "first two layers as two launches", t);
     }
 }
