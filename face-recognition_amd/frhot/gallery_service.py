@@ -82,6 +82,7 @@ class GalleryService:
             gallery = Gallery(ctx, dim, capacity)
         self.gallery = gallery
         self._lock = threading.RLock()
+        self._lock_depth = 0                       # how often the calling thread holds _lock through _locked()
         self._collections: dict[str, None] = {}
         self._keys: dict[tuple, int] = {}          # (collection, store_id) -> device key
         self._points: dict[int, dict] = {}         # row -> {"uid", "payload", "collection", "seq"}
@@ -91,6 +92,23 @@ class GalleryService:
 
     def close(self):
         self.gallery.close()
+
+    class _Locked:
+        def __init__(self, svc):
+            self.svc = svc
+
+        def __enter__(self):
+            self.svc._lock.acquire()
+            self.svc._lock_depth += 1
+
+        def __exit__(self, *exc):
+            self.svc._lock_depth -= 1
+            self.svc._lock.release()
+            return False
+
+    def _locked(self):
+        """The table lock, counting how deep the holder is in (read and written under the lock only)."""
+        return self._Locked(self)
 
     # ------------------------------------------------------------ collections
     def get_collections(self):
@@ -218,12 +236,42 @@ class GalleryService:
             return 404, {"message": "Embedding not found or invalid!"}
         return None
 
-    def _hits(self, scores, rows):
+    def _hits(self, scores, rows, seq0=None):
+        """Payloads of the rows a scan returned.  `seq0`: the write sequence number when the scan was
+        handed to the device without the table lock held; a row written after that may have been
+        scored with its previous occupant's vector and is left out (the search then counts as having
+        run between that occupant's deletion and the new point's insertion)."""
         out = []
         for s, r in zip(scores, rows):
-            if r >= 0 and int(r) in self._points:
-                out.append((float(s), self._points[int(r)]["payload"]))
+            p = self._points.get(int(r)) if r >= 0 else None
+            if p is not None and (seq0 is None or p["seq"] <= seq0):
+                out.append((float(s), p["payload"]))
         return out
+
+    # The table lock is NOT held while the device works on a search: enrolments and deletions of other
+    # requests go on meanwhile (the library orders their device writes with the scan on the context's
+    # stream), where qdrant_database_FE serves its handlers concurrently too.  A service whose search is
+    # a collective keeps the lock: every rank has to make its calls in the same order.
+    _search_holds_lock = False
+
+    class _Unlocked:
+        def __init__(self, lock, active):
+            self.lock, self.active = lock, active
+
+        def __enter__(self):
+            if self.active:
+                self.lock.release()
+
+        def __exit__(self, *exc):
+            if self.active:
+                self.lock.acquire()
+            return False
+
+    def _device_call(self):
+        """`with self._lock: ... with self._device_call(): <device work>`: the lock is given up for
+        the inner block (only when it is held exactly once, i.e. not from inside another locked call)."""
+        once = not self._search_holds_lock and self._lock_depth == 1
+        return self._Unlocked(self._lock, once)
 
     def search_point(self, collection_name, vector_embedding, store_id):
         """app.py:300-386."""
@@ -231,7 +279,7 @@ class GalleryService:
 
     def search_points(self, requests):
         """Batched form: [(collection_name, vector, store_id)] -> [(status, content)], one device scan."""
-        with self._lock:
+        with self._locked():
             out = [None] * len(requests)
             idx, vecs, keys = [], [], []
             for i, (col, vec, store_id) in enumerate(requests):
@@ -248,9 +296,11 @@ class GalleryService:
                 keys.append(k)
             if idx or self._always_search:
                 try:
-                    scores, rows = self._search_batch(vecs, keys)
+                    seq0 = self._seq
+                    with self._device_call():
+                        scores, rows = self._search_batch(vecs, keys)
                     for j, i in enumerate(idx):
-                        out[i] = (200, vote(self._hits(scores[j], rows[j])))
+                        out[i] = (200, vote(self._hits(scores[j], rows[j], seq0)))
                 except Exception as e:
                     for i in idx:
                         out[i] = (404, {"message": str(e)})
@@ -275,7 +325,7 @@ class GalleryService:
         the blur gate, legacy.py:125-129), from the same device call."""
         if not requests:
             return []
-        with self._lock:
+        with self._locked():
             out = [None] * len(requests)
             keys, bad = [], {}
             for i, (col, _crop, store_id) in enumerate(requests):
@@ -283,9 +333,11 @@ class GalleryService:
                     bad[i] = (404, {"message": "Collection name not found or invalid!"})
                 k = self._keys.get((col, store_id))
                 keys.append(self.NO_KEY if (k is None or i in bad) else k)
-            scores, rows, emb, *sharp = self.gallery.ctx.recognise(
-                self.gallery, [r[1] for r in requests], np.asarray(keys, np.int32), SEARCH_LIMIT, gamma=gamma,
-                want_embeddings=want_embeddings, want_sharpness=want_sharpness)
+            seq0 = self._seq
+            with self._device_call():
+                scores, rows, emb, *sharp = self.gallery.ctx.recognise(
+                    self.gallery, [r[1] for r in requests], np.asarray(keys, np.int32), SEARCH_LIMIT, gamma=gamma,
+                    want_embeddings=want_embeddings, want_sharpness=want_sharpness)
             for i in range(len(requests)):
                 e = emb[i].copy() if emb is not None else None
                 if i in bad:
@@ -293,7 +345,7 @@ class GalleryService:
                 elif keys[i] == self.NO_KEY:
                     out[i] = (200, {"message": "Point not found", "data": []}, e)
                 else:
-                    out[i] = (200, vote(self._hits(scores[i], rows[i])), e)
+                    out[i] = (200, vote(self._hits(scores[i], rows[i], seq0)), e)
                 if sharp:
                     out[i] += (float(sharp[0][i]),)
             return out

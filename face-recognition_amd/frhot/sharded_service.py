@@ -197,6 +197,7 @@ class _ShardedGallery:
 
 class ShardedGalleryService(GalleryService):
     _always_search = True
+    _search_holds_lock = True       # a search is a collective: the ranks' calls must come in one order
 
     def __init__(self, backend, rank: int, world: int, capacity_per_shard: int, dim: int, batch: int = 64,
                  host_staged: bool = False):

@@ -938,6 +938,75 @@ def test_gallery_write_f16_restores_bit_for_bit(gpu_ctx, tmp_path):
     svc2.close()
 
 
+def test_service_enrols_and_deletes_while_recognitions_are_in_flight(gpu_ctx):
+    """qdrant_database_FE serves inserts, deletes and searches concurrently (app.py:242-438); the
+    in-process service gives up its table lock while the device works on a recognition, so
+    enrolments and deletions (whose rows are used again) run between and beside the scans.  Every
+    recognition still names the person it asked for, and the table ends consistent."""
+    import threading
+    from frhot import synth
+    from frhot.gallery_service import GalleryService
+    svc = GalleryService(gpu_ctx, capacity=1024)
+    col = "S_Employees"
+    assert svc.create_collection(col)[0] == 201
+    stores = ["s0", "s1", "s2", "s3"]
+    crops = synth.crops(seed=123, n=len(stores), lo=120, hi=260)
+    emb = gpu_ctx.embed(crops, gamma=True)
+    for j, st in enumerate(stores):
+        assert svc.insert_point(col, list(emb[j]), f"fixed{j}", f"F{j}", st)[0] == 201
+    stop = threading.Event()
+    errors = []
+    counts = {"recognitions": 0, "mutations": 0}
+
+    def mutate():
+        rng = np.random.default_rng(5)
+        live = []
+        try:
+            i = 0
+            while not stop.is_set():
+                v = rng.standard_normal(4096).astype(np.float32)
+                st = stores[i % len(stores)]
+                assert svc.insert_point(col, list(v), f"temp{i}", f"T{i}", st)[0] == 201
+                live.append(i)
+                if len(live) > 3:
+                    assert svc.delete_point(col, f"temp{live.pop(0)}")[0] == 200
+                counts["mutations"] += 1
+                i += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    def recognise(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            while not stop.is_set():
+                pick = [int(x) for x in rng.integers(0, len(stores), size=int(rng.integers(1, 5)))]
+                out = svc.recognise_points([(col, crops[j], stores[j]) for j in pick], gamma=True)
+                for j, (status, content, _e) in zip(pick, out):
+                    assert status == 200 and content["message"] == "Point found", content
+                    score, payload = content["data"][0]
+                    assert payload["id"] == f"fixed{j}" and score > 0.999, (j, score, payload)
+                counts["recognitions"] += len(pick)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=mutate)] + [threading.Thread(target=recognise, args=(s,)) for s in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    import time
+    time.sleep(1.5)
+    stop.set()
+    for t in threads:
+        t.join(30)
+    assert not any(t.is_alive() for t in threads)
+    assert not errors, errors[:3]
+    assert counts["recognitions"] > 20 and counts["mutations"] > 20, counts
+    assert svc.point_count(col) == len(stores) + 3
+    for j, st in enumerate(stores):
+        status, content = svc.search_point(col, list(emb[j]), st)
+        assert status == 200 and content["data"][0][1]["id"] == f"fixed{j}"
+    svc.close()
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_api_end_to_end_concurrent_requests(gpu_ctx, fused):
     """The two routes served from the GPU context (frhot.api.create_app): enrol, then recognise

@@ -792,3 +792,47 @@ def test_crop_args_one_row_view_gets_a_usable_stride():
     wide = np.zeros((6, 10, 3), np.uint8)[:, 2:7]
     _keep, _ptrs, hw, strides = _crop_args([one, rev, wide])
     assert hw.tolist() == [[1, 7], [5, 4], [6, 5]] and strides.tolist() == [21, 12, 30]
+
+
+def test_search_does_not_hold_the_table_lock_while_the_device_works():
+    """An enrolment and a deletion complete while a search's scan is in flight (the reference's DB
+    service serves its handlers concurrently, qdrant_database_FE/app.py:242-438); a row that was
+    freed and written again during the scan is not reported with its new owner's payload."""
+    import threading
+    dim = 64
+    svc = _service(dim, 256)
+    gal = svc.gallery
+    col = "7_Employees"
+    assert svc.create_collection(col)[0] == 201
+    rng = np.random.default_rng(4)
+    va, vb, vc = (rng.standard_normal(dim).astype(np.float32) for _ in range(3))
+    assert svc.insert_point(col, va, "A", "Ann", 7)[0] == 201
+    assert svc.insert_point(col, vb, "B", "Bob", 7)[0] == 201
+    started, go = threading.Event(), threading.Event()
+    plain_search = gal.search
+
+    def slow_search(q, qkeys=None, k=5):
+        out = plain_search(q, qkeys, k)         # the scan sees Ann's vector in her row ...
+        started.set()
+        assert go.wait(10)                      # ... and is still "on the device" while the table changes
+        return out
+
+    gal.search = slow_search
+    answer = {}
+    t = threading.Thread(target=lambda: answer.update(res=svc.search_point(col, va, 7)))
+    t.start()
+    assert started.wait(10)
+    # while the scan is in flight: Ann is deleted and Cid enrolled, into the row Ann had
+    assert svc.delete_point(col, "A") == (200, {"message": "Point deleted"})
+    assert svc.insert_point(col, vc, "C", "Cid", 7)[0] == 201
+    assert svc.point_count(col) == 2
+    go.set()
+    t.join(10)
+    assert not t.is_alive()
+    status, content = answer["res"]
+    assert status == 200
+    # Ann's row scored 1.0 for the scan, but it belongs to Cid now: nobody is reported for it
+    assert all(p["id"] not in ("A", "C") for _score, p in content["data"])
+    gal.search = plain_search
+    status, content = svc.search_point(col, vc, 7)
+    assert status == 200 and content["data"] and content["data"][0][1]["id"] == "C"
