@@ -1254,9 +1254,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(const half_t* __restr
 // FUSE1 (the 224 x 224 layer after the 3-channel one): the patch is not fetched but COMPUTED.
 // x is then the network input [B,226,226,4] and w1/b1 the first layer's [64][64] weights and
 // bias as conv1_1_kernel takes them.  The 324 patch pixels are 21 groups of 16 (2 x 8 blocks,
-// and the last two columns); wave v makes
-// groups v, v+8, v+16 of the NEXT tile's patch while the current tile computes: the three
-// 8-byte tap loads of a group are issued in the L phase of taps 1/3/5 and its eight MFMAs
+// and the last two columns); wave v makes groups v, v+8, v+16 of the NEXT tile's patch while
+// the current tile computes: the three 8-byte tap loads of a group (its 3 x 3 windows of the
+// 20 x 20 x 4 input) are issued in the L phase of taps 1/3/5 and its eight MFMAs
 // (K = 36 in two 16x16x32, as in conv1_1_kernel), bias, ReLU, fp16 and four ds_write_b64 into
 // the swizzled patch rows run in the M phase of taps 2/4/6.  Patch pixels outside the image
 // are the layer's zero padding, not first-layer outputs: they are written as zeros.  The
