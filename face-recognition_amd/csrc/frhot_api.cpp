@@ -276,7 +276,7 @@ constexpr int kShareMinBatch = 192;
 // Enqueue the whole embed pipeline for B crops whose pixels sit at crops_dev.
 int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
                   const int32_t* strides, int B, unsigned flags, float* out_f32, void* out_q, int Dq,
-                  SecondHalfGate* gate = nullptr, int first_part = 0) {
+                  SecondHalfGate* gate = nullptr, int first_part = 0, bool parts_start_together = true) {
     if (!c->model) return fail(FRHOT_ESTATE, "frhot_model_load has not been called");
     if (B <= 0 || B > c->max_batch) return fail(FRHOT_ECAPACITY, "batch %d outside 1..%d", B, c->max_batch);
     if (!crops_dev || !offsets || !hw || !strides) return fail(FRHOT_EINVAL, "null crop arguments");
@@ -319,10 +319,11 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
 #ifdef FR_NO_SHARE
         const int share = 0;
 #else
-        // Not for a host call (its first part runs alone while the second is still being uploaded) and not
-        // for smaller batches, whose launches have too few rounds of tiles for half the CUs
+        // Not for a host call that is alone in the library (its first part runs by itself while the second is
+        // still being uploaded; a call that found another in flight has its crops on the device by the time
+        // the GPU reaches it) and not for smaller batches, whose launches have too few rounds of tiles for half the CUs
         // (conv stack at 32 / 64 / 128 faces 1.05 / 1.83 / 3.47 ms without shares, 1.12 / 1.87 / 3.55 with; 192 faces 5.23 against 5.05).
-        const int share = nparts > 1 && !gate && B >= kShareMinBatch ? (256 * n / B + 7) / 8 * 8 : 0;
+        const int share = nparts > 1 && parts_start_together && B >= kShareMinBatch ? (256 * n / B + 7) / 8 * 8 : 0;
 #endif
         if (part == 1) {
             if (gate) {
@@ -1163,7 +1164,7 @@ int frhot_embed(frhot_ctx* c, const uint8_t* const* crops, const int32_t* hw, co
     if (rc) return rc;
     rc = run_staged(c, lease.sl, st, [&]() -> int {
         int r = embed_enqueue(c, lease.sl.dev, st.offsets.data(), hw, st.packed_strides.data(), B, flags, c->emb_dev,
-                              nullptr, kFcN, &st, st.split_at);
+                              nullptr, kFcN, &st, st.split_at, !call.alone);
         if (r) return r;
         HIP_TRY(hipMemcpyAsync(lease.sl.emb_pin, c->emb_dev, (size_t)B * kFcN * 4, hipMemcpyDeviceToHost, c->stream));
         return FRHOT_OK;
@@ -1749,7 +1750,7 @@ static int recognise_impl(frhot_ctx* c, frhot_gallery* g, const uint8_t* const* 
     int64_t* const pin_r = (int64_t*)(sl.res_pin + (size_t)c->max_batch * 16 * 4);
     rc = run_staged(c, sl, st, [&]() -> int {
         hipStream_t s = c->stream;
-        int r = embed_enqueue(c, sl.dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D, &st, st.split_at);
+        int r = embed_enqueue(c, sl.dev, offsets.data(), hw, ps.data(), B, flags, c->emb_dev, c->q_dev, g->D, &st, st.split_at, !call.alone);
         if (r) return r;
         r = search_keyed_enqueue(g, c->q_dev, qkeys, c->qkeys_dev, B, k, c->res_s, c->res_r, sl.idx);
         if (r) return r;
