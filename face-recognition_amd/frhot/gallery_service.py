@@ -82,7 +82,7 @@ class GalleryService:
             gallery = Gallery(ctx, dim, capacity)
         self.gallery = gallery
         self._lock = threading.RLock()
-        self._lock_depth = 0                       # how often the calling thread holds _lock through _locked()
+        self._held = threading.local()             # .depth: how often the calling thread holds _lock through _locked()
         self._collections: dict[str, None] = {}
         self._keys: dict[tuple, int] = {}          # (collection, store_id) -> device key
         self._points: dict[int, dict] = {}         # row -> {"uid", "payload", "collection", "seq"}
@@ -99,15 +99,15 @@ class GalleryService:
 
         def __enter__(self):
             self.svc._lock.acquire()
-            self.svc._lock_depth += 1
+            self.svc._held.depth = getattr(self.svc._held, "depth", 0) + 1
 
         def __exit__(self, *exc):
-            self.svc._lock_depth -= 1
+            self.svc._held.depth -= 1
             self.svc._lock.release()
             return False
 
     def _locked(self):
-        """The table lock, counting how deep the holder is in (read and written under the lock only)."""
+        """The table lock, counting per thread how deep the holder is in."""
         return self._Locked(self)
 
     # ------------------------------------------------------------ collections
@@ -270,7 +270,7 @@ class GalleryService:
     def _device_call(self):
         """`with self._lock: ... with self._device_call(): <device work>`: the lock is given up for
         the inner block (only when it is held exactly once, i.e. not from inside another locked call)."""
-        once = not self._search_holds_lock and self._lock_depth == 1
+        once = not self._search_holds_lock and getattr(self._held, "depth", 0) == 1
         return self._Unlocked(self._lock, once)
 
     def search_point(self, collection_name, vector_embedding, store_id):

@@ -836,3 +836,20 @@ def test_search_does_not_hold_the_table_lock_while_the_device_works():
     gal.search = plain_search
     status, content = svc.search_point(col, vc, 7)
     assert status == 200 and content["data"] and content["data"][0][1]["id"] == "C"
+    # two searches at once: neither holds the lock while its scan runs (both reach the gallery before either returns)
+    inside, both = [], threading.Event()
+
+    def meet(q, qkeys=None, k=5):
+        inside.append(1)
+        if len(inside) == 2:
+            both.set()
+        assert both.wait(10), "the second search never reached the gallery while the first was in it"
+        return plain_search(q, qkeys, k)
+
+    gal.search = meet
+    ts = [threading.Thread(target=svc.search_point, args=(col, vb, 7)) for _ in range(2)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join(15)
+    assert not any(th.is_alive() for th in ts) and both.is_set()
