@@ -92,6 +92,36 @@ def test_layers_match_oracle(gpu_ctx, weights_q):
     assert np.abs(got6 - want[13]).max() <= 4e-3 * np.abs(want[13]).max()
 
 
+def test_first_layer_output_is_not_kept_in_device_memory(weights_f32):
+    """The embed path computes conv1_1 inside conv1_2's kernel: a context holds no buffer for its
+    output (6.4 MB per face of max_batch) until frhot_debug_read is asked for stage 10, which then
+    makes it with the stand-alone kernel."""
+    import torch
+    from frhot import synth
+    from frhot.engine import Context
+    from frhot.weights import pack_blob
+    n = 32
+    per_face = 226 * 226 * 64 * 2
+    ctx = Context(device=0, max_batch=n)
+    try:
+        ctx.load_model(pack_blob(weights_f32), input_scale=1.0 / 16.0)
+        imgs = synth.crops(seed=12, n=n, lo=120, hi=200)
+        ctx.embed(imgs)
+        ctx.embed(imgs)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        ctx.embed(imgs)
+        layer2 = ctx.debug_read(11, n)
+        assert torch.cuda.mem_get_info()[0] == free0          # neither the embed nor a later stage allocates
+        layer1 = ctx.debug_read(10, n)
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert n * per_face <= used <= n * per_face + (64 << 20), used
+        assert layer1.shape == (n, 226, 226, 64) and layer1[:, 1:-1, 1:-1].any() and layer2.any()
+        assert np.array_equal(ctx.debug_read(10, n), layer1)
+    finally:
+        ctx.close()
+
+
 def test_embedding_cosine(gpu_ctx, weights_f32, weights_q):
     """cosine(GPU descriptor, oracle descriptor) >= 0.9999 per face (tolerance of the north star)."""
     from frhot import synth
