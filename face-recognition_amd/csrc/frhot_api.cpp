@@ -973,7 +973,8 @@ static int ctx_init(frhot_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->img_max, sizeof(int) * B));
     HIP_TRY(hipMalloc((void**)&c->meta_dev, sizeof(CropMeta) * B));
     HIP_TRY(hipMalloc(&c->fc6_out, (size_t)B * kFcN * 2));
-    HIP_TRY(hipMalloc((void**)&c->partial, (size_t)kFc6Split * B * kFcN * 4));
+    // fp32 split-K slabs of fc6, then of fc7 (also the conv kernels' 1 KiB dump)
+    HIP_TRY(hipMalloc((void**)&c->partial, (size_t)(kFc6Split > kFc7Split ? kFc6Split : kFc7Split) * B * kFcN * 4));
     HIP_TRY(hipMalloc((void**)&c->emb_dev, (size_t)B * kFcN * 4));
     HIP_TRY(hipMalloc(&c->q_dev, (size_t)B * kFcN * 2));
     HIP_TRY(hipMalloc((void**)&c->qkeys_dev, (size_t)B * 4));

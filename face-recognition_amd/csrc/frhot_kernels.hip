@@ -3672,6 +3672,17 @@ hipError_t launch_fc_splitk(const void* x, const void* w, float* partial, int M,
         FR_CHECK_LAUNCH();
         return hipSuccess;
     }
+    if (M <= 256) {
+        // up to a batch of 256: 128-row tiles, two blocks per CU (64 KiB of LDS each) instead of one of 96 KiB.  The
+        // kernel's two-stage ring leaves one stage in flight, so a second block per CU is what hides the weights' HBM
+        // latency: fc6 + fc7 of 256 faces 0.147 -> 0.134 ms, same bits (the K order of an output element is the same).
+        using Mid = GemmCore<128, 128, 2, 2, false>;
+        dim3 grid(N / 128, (M + 127) / 128, splitk);
+        hipLaunchKernelGGL((fc_splitk_kernel<128, 128, 2, 2>), grid, dim3(256), 2 * Mid::SB, s, (const half_t*)x,
+                           (const half_t*)w, partial, M, N, K, kper);
+        FR_CHECK_LAUNCH();
+        return hipSuccess;
+    }
     dim3 grid(N / 128, (M + 255) / 256, splitk);
     hipLaunchKernelGGL((fc_splitk_kernel<256, 128, 2, 2>), grid, dim3(256), 2 * FcCore::SB, s, (const half_t*)x,
                        (const half_t*)w, partial, M, N, K, kper);
@@ -4126,6 +4137,9 @@ hipError_t kernels_init() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)fc_splitk_kernel<256, 128, 2, 2>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FcCore::SB);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fc_splitk_kernel<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * GemmCore<128, 128, 2, 2, false>::SB);
     if (e != hipSuccess) return e;
     static const int combos[][2] = {{5, 64}, {5, 128}, {5, 256}, {10, 64}, {10, 128}, {16, 64}};
     for (const auto& c : combos)

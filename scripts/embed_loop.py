@@ -46,6 +46,8 @@ with torch.cuda.stream(stream):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     st = ctx.stage_ms()
-    print('batch %d, %d steps%s: %.3f ms per batch; stages %s' % (B, steps, ', each awaited' if gap else '', dt * 1e3,
-                                                                 {k: round(v, 3) for k, v in st.items()}))
+    import hashlib
+    digest = hashlib.sha256(q.cpu().numpy().tobytes()).hexdigest()[:12]
+    print('batch %d, %d steps%s: %.3f ms per batch; stages %s; descriptors %s' % (B, steps, ', each awaited' if gap else '', dt * 1e3,
+                                                                               {k: round(v, 3) for k, v in st.items()}, digest))
     ctx.close()

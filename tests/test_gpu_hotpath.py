@@ -115,7 +115,7 @@ def test_first_layer_output_is_not_kept_in_device_memory(weights_f32):
         assert torch.cuda.mem_get_info()[0] == free0          # neither the embed nor a later stage allocates
         layer1 = ctx.debug_read(10, n)
         used = free0 - torch.cuda.mem_get_info()[0]
-        assert n * per_face <= used <= n * per_face + (64 << 20), used
+        assert abs(used - n * per_face) <= (32 << 20), used      # (the runtime hands out memory in pieces of its own size)
         assert layer1.shape == (n, 226, 226, 64) and layer1[:, 1:-1, 1:-1].any() and layer2.any()
         assert np.array_equal(ctx.debug_read(10, n), layer1)
     finally:
