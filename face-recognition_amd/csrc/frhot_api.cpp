@@ -271,7 +271,7 @@ struct SecondHalfGate {
 };
 
 constexpr int kShareLayers = 6;     // conv layers 1..6 (conv1_2 .. conv3_3) are launched with a share of the CUs when a batch runs in two parts
-constexpr int kShareMinBatch = 192;
+constexpr int kShareMinBatch = 192, kShareMaxBatch = 320;
 
 // Enqueue the whole embed pipeline for B crops whose pixels sit at crops_dev.
 int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, const int32_t* hw,
@@ -322,8 +322,11 @@ int embed_enqueue(frhot_ctx* c, const void* crops_dev, const int64_t* offsets, c
         // Not for a host call that is alone in the library (its first part runs by itself while the second is
         // still being uploaded; a call that found another in flight has its crops on the device by the time
         // the GPU reaches it) and not for smaller batches, whose launches have too few rounds of tiles for half the CUs
-        // (conv stack at 32 / 64 / 128 faces 1.05 / 1.83 / 3.47 ms without shares, 1.12 / 1.87 / 3.55 with; 192 faces 5.23 against 5.05).
-        const int share = nparts > 1 && parts_start_together && B >= kShareMinBatch ? (256 * n / B + 7) / 8 * 8 : 0;
+        // (conv stack at 32 / 64 / 128 faces 1.05 / 1.83 / 3.47 ms without shares, 1.12 / 1.87 / 3.55 with; 192 faces 5.23 against 5.05),
+        // nor for larger ones, whose launches have rounds enough to fill the chip either way (embed of 256 / 320 faces
+        // 7.24 -> 7.18 / 9.02 -> 8.98 ms with shares, 384 / 512 / 1024 faces 10.88 -> 10.93 / 13.81 -> 13.94 / 26.65 -> 26.88).
+        const int share = nparts > 1 && parts_start_together && B >= kShareMinBatch && B <= kShareMaxBatch
+                              ? (256 * n / B + 7) / 8 * 8 : 0;
 #endif
         if (part == 1) {
             if (gate) {
